@@ -1,0 +1,254 @@
+/* cedarhip.h — C-ABI of the MI355X-native transient/DC Newton engine for CedarSim-style circuits.
+ *
+ * This is the drop-in boundary described in DESIGN.md §2.  CedarSim (Julia) has NO FFI for this
+ * path today (the only ccall in the reference is :jl_generating_output, src/CedarSim.jl:44); the
+ * hot path runs inside un-vendored Julia/C packages (DAECompiler, Sundials IDA, NonlinearSolve).
+ * Each entry point below therefore cites the reference *interface* whose work it replaces; the
+ * Julia-side binding a maintainer would add is shown in INTEGRATION.md and cedarsim.jl_amd/julia/.
+ *
+ * Conventions
+ *   - plain C, no torch types; all arrays are caller-owned and copied by the engine unless stated.
+ *   - node ids: 0 is ground, 1..n_nodes are circuit nodes.
+ *   - MNA solution vectors ("x_mna") have length n_nodes + n_branches:
+ *       x_mna[0..n_nodes)            node voltages of node 1..n_nodes
+ *       x_mna[n_nodes + k]           current of the k-th branch device (V, L, E in device order),
+ *                                    flowing from net+ to net- through the device — the sign
+ *                                    convention of branch!() (src/simulate_ir.jl:112-120).
+ *   - all functions return 0 on success or a negative CH_ERR_* code; they never throw.
+ *   - a ch_ctx / ch_circuit is not thread-safe; use one host thread per GPU (one process per GPU).
+ */
+#ifndef CEDARHIP_H
+#define CEDARHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CH_NAN (__builtin_nan(""))
+
+/* ---- error codes (map to SciML retcodes on the Julia side) ---- */
+enum {
+  CH_OK = 0,
+  CH_ERR_INVALID = -1,      /* bad argument / malformed description (CedarError)            */
+  CH_ERR_SINGULAR = -2,     /* singular Jacobian (LinearAlgebra.SingularException)          */
+  CH_ERR_MAXITERS = -3,     /* DC did not converge: ReturnCode.InitialFailure / MaxIters    */
+  CH_ERR_DTMIN = -4,        /* step size underflow: ReturnCode.DtLessThanMin                */
+  CH_ERR_DEVICE = -5,       /* HIP runtime failure                                          */
+  CH_ERR_UNSUPPORTED = -6,  /* feature outside the engine's scope                           */
+  CH_ERR_MAXSTEPS = -7      /* transient exceeded max_steps: ReturnCode.MaxIters            */
+};
+
+/* ---- device kinds (reference device functors, src/simpledevices.jl, src/vasim.jl) ---- */
+enum {
+  CH_DEV_R = 1,    /* SimpleResistor   simpledevices.jl:65-77   par[0]=r                      */
+  CH_DEV_C = 2,    /* SimpleCapacitor  simpledevices.jl:105-109 par[0]=c                      */
+  CH_DEV_L = 3,    /* SimpleInductor   simpledevices.jl:128-132 par[0]=l     (branch)         */
+  CH_DEV_V = 4,    /* VoltageSource    simpledevices.jl:288-300 ipar[0]=source (branch)       */
+  CH_DEV_I = 5,    /* CurrentSource    simpledevices.jl:327-339 ipar[0]=source                */
+  CH_DEV_VCVS = 6, /* vcvs             simpledevices.jl:347-356 par[0]=gain  (branch)         */
+  CH_DEV_VCCS = 7, /* vccs             simpledevices.jl:364-373 par[0]=gain                   */
+  CH_DEV_MOS = 8   /* BSIM4 functor (VA-generated in the reference, vasim.jl:853-867):
+                      nodes d,g,s,b ; ipar[0]=model ; par = {w,l,nf,as,ad,ps,pd,-}            */
+};
+#define CH_DEV_NNODE 4
+#define CH_DEV_NPAR 8
+#define CH_DEV_NIPAR 2
+
+/* MOS instance parameter slots inside par[] */
+enum { CH_MOS_W = 0, CH_MOS_L = 1, CH_MOS_NF = 2, CH_MOS_AS = 3, CH_MOS_AD = 4, CH_MOS_PS = 5, CH_MOS_PD = 6 };
+
+/* ---- source waveforms (src/spectre_env.jl:144-176) ---- */
+enum {
+  CH_SRC_DC = 0,
+  CH_SRC_PWL = 1,   /* pwl(wave)            spectre_env.jl:43-69,144-151 */
+  CH_SRC_PULSE = 2, /* pulse(v1,v2,td,tr,tf,pw,period)  :153-166 ; par = v1 v2 td tr tf pw period */
+  CH_SRC_SIN = 3    /* spsin(vo,va,freq,td,theta,phase,ncycles) :169-176                           */
+};
+#define CH_SRC_NPAR 8
+
+/* ---- BSIM4 model-card parameter indices ---- */
+enum {
+#define P(n, d) CH_B4_##n,
+#define B(n, d) CH_B4_##n, CH_B4_l##n, CH_B4_w##n, CH_B4_p##n,
+#define I(n)
+#include "cedarhip_bsim4_params.def"
+  CH_B4_NPAR
+};
+
+/* ---- sweepable parameter slots: the runtime fields of ParamSim's `p` (circuitodesystem.jl:66-97) ---- */
+enum {
+  CH_SLOT_DEV_PAR = 1,   /* a = device index, b = par index            */
+  CH_SLOT_MODEL_PAR = 2, /* a = model index,  b = CH_B4_* index        */
+  CH_SLOT_SRC_DC = 3,    /* a = source index  (dc AND constant tran)   */
+  CH_SLOT_SRC_PAR = 4,   /* a = source index, b = par index            */
+  CH_SLOT_TEMP = 5,      /* SimSpec.temp  (simulate_ir.jl:15)          */
+  CH_SLOT_GMIN = 6,      /* SimSpec.gmin  (simulate_ir.jl:16)          */
+  CH_SLOT_DEV_MULT = 7   /* a = device index: ParallelInstances m      */
+};
+
+/* Flat circuit description = what a StampExtract overlay over the netlist closure records
+ * (SURVEY §3.5): device type, field values, net ids, multiplier. */
+typedef struct ch_desc {
+  int32_t n_nodes; /* excluding ground */
+  /* devices */
+  int32_t n_dev;
+  const int32_t* dev_kind; /* [n_dev] CH_DEV_*                                   */
+  const int32_t* dev_node; /* [n_dev*CH_DEV_NNODE] node ids (unused = 0)         */
+  const int32_t* dev_ipar; /* [n_dev*CH_DEV_NIPAR]                               */
+  const double* dev_par;   /* [n_dev*CH_DEV_NPAR] (NaN = not given)              */
+  const double* dev_mult;  /* [n_dev] multiplicity m (simulate_ir.jl:56-75)      */
+  /* sources */
+  int32_t n_src;
+  const int32_t* src_kind;    /* [n_src] CH_SRC_* : transient waveform            */
+  const double* src_dc;       /* [n_src] value in :dcop mode (simpledevices.jl:290-291) */
+  const double* src_par;      /* [n_src*CH_SRC_NPAR]                              */
+  const int32_t* src_pwl_ofs; /* [n_src+1] offsets into pwl_t/pwl_y               */
+  const double* pwl_t;
+  const double* pwl_y;
+  /* BSIM4 model cards */
+  int32_t n_model;
+  const double* model_par; /* [n_model*CH_B4_NPAR], NaN = not given */
+  /* SimSpec (simulate_ir.jl:12-20) */
+  double temp;  /* Celsius, default 27 */
+  double gmin;  /* default 1e-12       */
+  double scale; /* default 1           */
+  /* sweepable slots */
+  int32_t n_slot;
+  const int32_t* slot_kind; /* [n_slot] CH_SLOT_* */
+  const int32_t* slot_a;    /* [n_slot] */
+  const int32_t* slot_b;    /* [n_slot] */
+  /* observables saved by ch_tran: node voltages and branch currents */
+  int32_t n_obs;
+  const int32_t* obs_kind;  /* [n_obs] 0 = node voltage (index = node id), 1 = branch current (index = device index) */
+  const int32_t* obs_index; /* [n_obs] */
+} ch_desc;
+
+/* Statistics — the fields CedarSim accumulates from NLStats/DEStats (src/dcop.jl:63-67,134-139) */
+typedef struct ch_stats {
+  int64_t nf;              /* residual (device) evaluations                     */
+  int64_t njacs;           /* Jacobian evaluations                              */
+  int64_t nfactors;        /* LU factorisations                                 */
+  int64_t nsolve;          /* triangular solves                                 */
+  int64_t nnonliniter;     /* Newton iterations (max over blocks, summed over samples: see DESIGN.md) */
+  int64_t nnonlinconvfail; /* Newton convergence failures                       */
+  int64_t naccept;         /* accepted time steps                               */
+  int64_t nreject;         /* rejected time steps (LTE)                         */
+  int64_t nrestarts;       /* DC random restarts used                           */
+  double wall_seconds;     /* host wall-clock inside the call                   */
+  double dc_seconds;       /* of which DC initialisation                        */
+  double device_seconds;   /* sum of dominant-kernel durations measured with HIP events (0 for oracle) */
+  int64_t n_kernel_launches;
+} ch_stats;
+
+/* CedarDCOp options (src/dcop.jl:24-28, 53-94) */
+typedef struct ch_dc_opts {
+  double abstol;      /* residual inf-norm tolerance, default 1e-10 (dcop.jl:28)          */
+  int32_t maxiters;   /* default 200 (dcop.jl:53)                                          */
+  int32_t n_restarts; /* default 10 (num_trajectories, dcop.jl:53)                         */
+  uint64_t seed;      /* RNG seed for u0 = 1e-7*randn (dcop.jl:60)                         */
+  int32_t tran_mode;  /* 0: :dcop (sources at .dc), 1: :tranop (sources at tran(t=0))      */
+  double dv_max;      /* Newton damping: max node-voltage change per iteration (0 = off)   */
+  const double* x0;   /* optional initial guess [n_samples][n_mna] or NULL                 */
+} ch_dc_opts;
+
+/* transient options — solve(prob, IDA(); abstol, reltol) (src/sweeps.jl:456) */
+typedef struct ch_tran_opts {
+  double abstol;     /* default 1e-6 */
+  double reltol;     /* default 1e-3 */
+  int32_t max_order; /* 1..5 variable-order BDF, default 5 (IDA) */
+  double dtmin;      /* default 1e-18*(t1-t0)... 0 = auto */
+  double dtmax;      /* 0 = auto ((t1-t0)/10) */
+  double dt0;        /* initial step, 0 = auto */
+  int32_t max_steps; /* 0 = 10 000 000 */
+  int32_t newton_maxiters; /* default 10 */
+  int32_t n_saveat;        /* 0: save every accepted step */
+  const double* saveat;    /* [n_saveat] increasing times to save (dense output by interpolation) */
+  ch_dc_opts dc;           /* initialisation (CedarDCOp) */
+  int32_t skip_dc;         /* 1: start from dc.x0 as given (u0 passed by the caller, test/common.jl:36-43) */
+} ch_tran_opts;
+
+typedef struct ch_ctx ch_ctx;
+typedef struct ch_circuit ch_circuit;
+typedef struct ch_result ch_result;
+
+typedef struct ch_info {
+  int32_t n_nodes, n_branches, n_mna; /* MNA sizes of the description                          */
+  int32_t n_unknowns;                 /* unknowns after structural simplification              */
+  int32_t n_known;                    /* nodes eliminated as known (grounded-source chains)    */
+  int32_t n_alias;                    /* nodes merged by 0 V ammeter sources                   */
+  int32_t n_components;               /* independent diagonal blocks of the Jacobian           */
+  int32_t max_component;              /* unknowns in the largest block                         */
+  int32_t n_classes;                  /* structurally distinct blocks                          */
+  int32_t n_mos, n_mos_classes;       /* MOS instances, distinct (model,geometry) classes      */
+  int32_t path;                       /* 1 = fused block kernel, 2 = sparse level-scheduled    */
+  int64_t nnz_jac, nnz_lu;            /* sparse path only                                      */
+  int32_t n_samples;
+} ch_info;
+
+/* ---- defaults ---- */
+void ch_dc_opts_default(ch_dc_opts*);
+void ch_tran_opts_default(ch_tran_opts*);
+
+/* ---- context: one per GPU.  Replaces: nothing in the reference (CPU only). ---- */
+ch_ctx* ch_create(int device_id, char* err, size_t errlen);
+void ch_destroy(ch_ctx*);
+const char* ch_last_error(ch_ctx*);
+
+/* ---- circuit: replaces CircuitIRODESystem(circuit) + DAEProblem(sys, …) construction
+ *      (src/circuitodesystem.jl:147-164, src/sweeps.jl:444): structural analysis done once. ---- */
+ch_circuit* ch_circuit_build(ch_ctx*, const ch_desc*);
+void ch_circuit_free(ch_circuit*);
+int ch_circuit_info(ch_circuit*, ch_info*);
+
+/* ---- samples: replaces remake(prob, p=sim) over the sweep (src/sweeps.jl:471-482). ----
+ * values is slot-major: values[slot_i * (sample_hi-sample_lo) + (s - sample_lo)]. */
+int ch_set_samples(ch_circuit*, int32_t n_samples);
+int ch_set_params(ch_circuit*, int32_t sample_lo, int32_t sample_hi, int32_t n_slots,
+                  const int32_t* slot_ids, const double* values);
+
+/* ---- DC operating point: replaces initialize_dae!(…, ::CedarDCOp) + bootstrapped_nlsolve
+ *      (src/dcop.jl:53-94,157-200).  x_out: [n_samples][n_mna]. status_out: [n_samples] or NULL. ---- */
+int ch_dc(ch_circuit*, const ch_dc_opts*, double* x_out, int32_t* status_out, ch_stats* stats);
+
+/* ---- transient: replaces solve(prob, IDA(); abstol, reltol, initializealg=CedarDCOp())
+ *      (src/sweeps.jl:456, test/gf180_dff.jl:25). ---- */
+int ch_tran(ch_circuit*, double t0, double t1, const ch_tran_opts*, ch_result** out);
+
+int64_t ch_result_n_times(const ch_result*);
+const double* ch_result_times(const ch_result*);  /* [n_times]                                  */
+const double* ch_result_values(const ch_result*); /* [n_obs][n_times][n_samples]                */
+const double* ch_result_final_state(const ch_result*); /* [n_samples][n_mna] at the last time   */
+int ch_result_stats(const ch_result*, ch_stats*);
+int ch_result_status(const ch_result*);           /* CH_OK or CH_ERR_*                          */
+void ch_result_free(ch_result*);
+
+/* ---- one residual/Jacobian evaluation: replaces prob.f.f(out,du,u,p,t) and
+ *      prob.f.jac(J,du,u,p,γ,t) (benchmarks/benchmark_common.jl:138,155).
+ *      Evaluates on the GPU at x_mna for sample `sample`:
+ *        F = i(x,t) + alpha0*q(x)   (history term excluded),  Q = q(x),
+ *        J = di/dx + alpha0*dq/dx as dense row-major [n_mna*n_mna] (rows/cols of eliminated
+ *        unknowns are returned as identity rows so the matrix stays usable by a host LU).
+ *      mode: 0 = :dcop source values, 1 = :tran source values at t. ---- */
+int ch_eval(ch_circuit*, int32_t sample, const double* x_mna, double t, double alpha0, int32_t mode,
+            double* F_out, double* Q_out, double* J_out);
+
+/* ---- BSIM4 device evaluation only (roofline kernel): evaluates every MOS instance at the
+ *      given terminal voltages.  v: [n_mos][4] (d,g,s,b); out: [n_mos][40] =
+ *      {i[4], q[4], g[16], c[16]} per instance.  Used by the parity tests and bench. ---- */
+int ch_mos_eval(ch_circuit*, int32_t sample, const double* v, double* out);
+
+/* ---- names of BSIM4 parameters (for host-side card parsing) ---- */
+int32_t ch_bsim4_npar(void);
+const char* ch_bsim4_param_name(int32_t idx);
+int32_t ch_bsim4_param_ignored(const char* name); /* 1 if accepted-and-ignored */
+
+/* ---- library/kernel introspection ---- */
+const char* ch_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CEDARHIP_H */
