@@ -1,0 +1,872 @@
+// ch_engine.hip — host side of the engine: contexts, circuits, parameter tables, the sequential
+// adaptive time stepper and the C-ABI of include/cedarhip.h.
+//
+// Division of labour (BASELINE.json north_star): the outer adaptive time stepper and all one-off
+// analysis stay on the host; every Newton solve runs on the GPU (ch_kernels.hpp).  Per step
+// attempt the host (1) evaluates the source waveforms at t_new and uploads the few known-node /
+// source values, (2) launches ONE fused Newton kernel + a tiny reduction, (3) reads back a 64-byte
+// summary (converged?, iterations, local-error norms for orders k-1,k,k+1) and decides
+// accept/reject, next step and next order — the job IDA does in the reference (src/sweeps.jl:456).
+// There is NO CPU fallback: without a HIP device ch_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cedarhip.h"
+#include "ch_analysis.hpp"
+#include "ch_bsim4.hpp"
+#include "ch_kernels.hpp"
+
+using namespace chip;
+using hclock = std::chrono::steady_clock;
+
+#define HIPCHK(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) { set_err(std::string(#call) + ": " + hipGetErrorString(e_)); return CH_ERR_DEVICE; } \
+  } while (0)
+
+struct ch_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+};
+
+namespace {
+
+// ---- RNG: splitmix64 + Box-Muller, as specified for the DC initial guess u0 = 1e-7*randn (dcop.jl:60)
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed) {}
+  uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+  double uniform() { return ((next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+  double normal() { double u1 = uniform(), u2 = uniform(); return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2); }
+};
+
+// ---- source waveforms (src/spectre_env.jl:15-21, :43-69, :153-166, :169-176) ----
+int find_t_in_ts(const std::vector<double>& ts, double t) {
+  int idx = (int)(std::lower_bound(ts.begin(), ts.end(), t) - ts.begin()) + 1;
+  if (idx <= (int)ts.size() && ts[idx - 1] == t) return idx + 1;  // a break point belongs to the next segment
+  return idx;
+}
+double pwl_at_time(const double* ts, const double* ys, int n, double t) {
+  if (n == 0) return 0.0;
+  int i = (int)(std::lower_bound(ts, ts + n, t) - ts) + 1;
+  if (i <= n && ts[i - 1] == t) ++i;
+  if (i <= 1) return ys[0];
+  if (i > n) return ys[n - 1];
+  if (ys[i - 2] == ys[i - 1]) return ys[i - 1];
+  if (ts[i - 1] == ts[i - 2]) return 0.5 * (ys[i - 2] + ys[i - 1]);
+  return ys[i - 2] + (t - ts[i - 2]) * ((ys[i - 1] - ys[i - 2]) / (ts[i - 1] - ts[i - 2]));
+}
+double sind(double deg) { return std::sin(std::fmod(deg, 360.0) * (3.14159265358979323846 / 180.0)); }
+// mode 0 :dcop, 1 :tran at t, 2 :tranop (t = 0)
+double source_value(const HSource& s, const double* par, double dc, double t, int mode) {
+  if (mode == 0) return dc;
+  if (mode == 2) t = 0.0;
+  switch (s.kind) {
+    case CH_SRC_DC: return par[0];
+    case CH_SRC_PWL: return pwl_at_time(s.ts.data(), s.ys.data(), (int)s.ts.size(), t);
+    case CH_SRC_PULSE: {
+      const double td = par[2], tr = par[3], tf = par[4], pw = par[5], per = par[6];
+      const double ts[4] = {td, td + tr, td + tr + pw, td + tr + pw + tf}, ys[4] = {par[0], par[1], par[1], par[0]};
+      return pwl_at_time(ts, ys, 4, std::isfinite(per) ? std::fmod(t, per) : t);
+    }
+    case CH_SRC_SIN: {
+      const double vo = par[0], va = par[1], f = par[2], td = par[3], th = par[4], ph = par[5], nc = par[6];
+      if (td < t && t < nc / f) return vo + va * std::exp(-(t - td) * th) * sind(360.0 * f * (t - td) + ph);
+      return vo + va * sind(ph);
+    }
+  }
+  return 0.0;
+}
+void source_breakpoints(const HSource& s, const double* par, double t0, double t1, std::vector<double>& out) {
+  if (s.kind == CH_SRC_PWL) { for (double t : s.ts) if (t > t0 && t < t1) out.push_back(t); }
+  else if (s.kind == CH_SRC_PULSE) {
+    const double td = par[2], tr = par[3], tf = par[4], pw = par[5], per = par[6];
+    const double c[4] = {td, td + tr, td + tr + pw, td + tr + pw + tf};
+    if (!std::isfinite(per) || per <= 0) { for (double t : c) if (t > t0 && t < t1) out.push_back(t); }
+    else { long k0 = std::max(0L, (long)std::floor(t0 / per) - 1); for (long k = k0; k * per < t1 && (k - k0) < 10000000; ++k) for (double tc : c) { double t = tc + k * per; if (t > t0 && t < t1) out.push_back(t); } }
+  } else if (s.kind == CH_SRC_SIN) { if (par[3] > t0 && par[3] < t1) out.push_back(par[3]); }
+}
+
+// variable-coefficient BDF helpers: tau[0] = t_new, tau[1..] history (newest first)
+void bdf_coeffs(const double* tau, int k, double* alpha) {
+  double a0 = 0;
+  for (int m = 1; m <= k; ++m) a0 += 1.0 / (tau[0] - tau[m]);
+  alpha[0] = a0;
+  for (int j = 1; j <= k; ++j) {
+    double num = 1, den = 1;
+    for (int m = 1; m <= k; ++m) if (m != j) num *= (tau[0] - tau[m]);
+    for (int m = 0; m <= k; ++m) if (m != j) den *= (tau[j] - tau[m]);
+    alpha[j] = num / den;
+  }
+}
+void extrap_weights(const double* tau, int np, double* w) {
+  for (int j = 1; j <= np; ++j) { double v = 1; for (int i = 1; i <= np; ++i) if (i != j) v *= (tau[0] - tau[i]) / (tau[j] - tau[i]); w[j] = v; }
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; return hipMalloc((void**)&p, std::max<size_t>(1, count) * sizeof(T)); }
+  hipError_t upload(const std::vector<T>& h, hipStream_t st) {
+    hipError_t e = hipSuccess;
+    if (h.size() != n || !p) e = alloc(h.size());
+    if (e != hipSuccess) return e;
+    if (h.empty()) return hipSuccess;
+    e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);
+  }
+};
+
+constexpr int NSLOT = 8;  // 7 history points + 1 candidate
+
+}  // namespace
+
+struct ch_result {
+  std::vector<double> times, values, final_state;
+  ch_stats stats;
+  int status = CH_OK;
+  int n_obs = 0, S = 1;
+};
+
+struct ch_circuit {
+  ch_ctx* ctx = nullptr;
+  // ---- description ----
+  int n_nodes = 0;
+  std::vector<HDev> dev;
+  std::vector<HSource> src;
+  std::vector<std::vector<double>> model;
+  double temp = 27, gmin = 1e-12, scale = 1;
+  std::vector<int> slot_kind, slot_a, slot_b, obs_kind, obs_index;
+  Analysis A;
+  // ---- samples ----
+  int S = 1;
+  std::vector<std::vector<double>> slot_val;  // [n_slot][S] or empty
+  bool dirty = true;
+  int Spar = 1, Ssrc = 1, Smos = 1, Sgmin = 1;
+  std::vector<double> h_src_dc, h_src_par;  // [Ssrc][nsrc], [Ssrc][nsrc][8]
+  std::vector<int> mos_cls;                 // [n_mos]
+  int n_cls = 0;
+  // ---- device buffers ----
+  DevBuf<int> d_comp_class, d_comp_uofs, d_comp_dofs, d_gl_ptr, d_dkind, d_dterm, d_dsrc, d_dcls, d_dhdev, d_obs_unk, d_moscls_inst;
+  DevBuf<ClassMeta> d_classes;
+  DevBuf<uint16_t> d_gl_src;
+  DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ;
+  DevBuf<unsigned char> d_dmask, d_active;
+  DevBuf<BlockOut> d_out;
+  DevBuf<Summary> d_sum;
+  Summary* h_sum = nullptr;     // pinned
+  double* h_stage = nullptr;    // pinned staging for kv/srcv uploads
+  size_t h_stage_n = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  size_t lds_bytes = 0;
+  NewtonArgs base;              // structure pointers filled once
+  // stats
+  double device_ms = 0; long n_launch = 0;
+
+  std::string& err() { return ctx->err; }
+  void set_err(const std::string& s) { ctx->err = s; }
+
+  ~ch_circuit() {
+    if (h_sum) (void)hipHostFree(h_sum);
+    if (h_stage) (void)hipHostFree(h_stage);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  int upload_structure() {
+    hipStream_t st = ctx->stream;
+    std::vector<ClassMeta> cms; std::vector<int> ptr; std::vector<uint16_t> srcs;
+    for (const CompClass& c : A.classes) {
+      ClassMeta m; m.nc = c.nc; m.ndev = c.ndev;
+      m.mat_ptr_ofs = (int)ptr.size(); ptr.insert(ptr.end(), c.mat_ptr.begin(), c.mat_ptr.end());
+      m.vec_ptr_ofs = (int)ptr.size(); ptr.insert(ptr.end(), c.vec_ptr.begin(), c.vec_ptr.end());
+      m.mat_src_ofs = (int)srcs.size(); srcs.insert(srcs.end(), c.mat_src.begin(), c.mat_src.end());
+      m.vec_src_ofs = (int)srcs.size(); srcs.insert(srcs.end(), c.vec_src.begin(), c.vec_src.end());
+      cms.push_back(m);
+    }
+    std::vector<int> dkind, dterm, dsrc, dhdev;
+    for (const EDev& e : A.edev) { dkind.push_back(e.kind); for (int k = 0; k < 4; ++k) dterm.push_back(e.term[k]); dsrc.push_back(e.src < 0 ? 0 : e.src); dhdev.push_back(e.hdev); }
+    std::vector<unsigned char> dm(A.n_unk, 0);
+    for (int u = 0; u < A.n_unk; ++u) dm[u] = (A.diff_mask[u] ? 1 : 0) | (A.unk_mna[u] >= n_nodes ? 2 : 0);
+    std::vector<int> obs_unk;
+    for (size_t o = 0; o < obs_kind.size(); ++o) {
+      int u = -1;
+      if (obs_kind[o] == 0) u = A.node_unknown[obs_index[o]];
+      else { int b = dev[obs_index[o]].branch; u = b >= 0 ? A.branch_unknown[b] : -1; }
+      obs_unk.push_back(u);
+    }
+    HIPCHK(d_classes.upload(cms, st)); HIPCHK(d_gl_ptr.upload(ptr, st)); HIPCHK(d_gl_src.upload(srcs, st));
+    HIPCHK(d_comp_class.upload(A.comp_class, st)); HIPCHK(d_comp_uofs.upload(A.comp_uofs, st)); HIPCHK(d_comp_dofs.upload(A.comp_dofs, st));
+    HIPCHK(d_dkind.upload(dkind, st)); HIPCHK(d_dterm.upload(dterm, st)); HIPCHK(d_dsrc.upload(dsrc, st)); HIPCHK(d_dhdev.upload(dhdev, st));
+    HIPCHK(d_dmask.upload(dm, st)); HIPCHK(d_obs_unk.upload(obs_unk, st));
+    HIPCHK(d_sum.alloc(1));
+    HIPCHK(hipHostMalloc((void**)&h_sum, sizeof(Summary)));
+    HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+    size_t ld = 0;
+    for (const CompClass& c : A.classes) ld = std::max(ld, (size_t)c.ndev * 40 + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 8 * (size_t)c.nc);
+    lds_bytes = ld * sizeof(double);
+    if (lds_bytes > 150 * 1024) { set_err("a Jacobian block needs more LDS than one CU has; the sparse path for large coupled blocks is not built yet"); return CH_ERR_UNSUPPORTED; }
+    if (lds_bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    return CH_OK;
+  }
+
+  // value of slot `kind` for sample s or the base value
+  bool slot_set(int i) const { return !slot_val[i].empty(); }
+
+  // ------------------------------------------------------------------------------------------
+  // (Re)build all per-sample parameter tables: remake(prob, p = sim) for every sample at once.
+  int finalize_params() {
+    if (!dirty) return CH_OK;
+    hipStream_t st = ctx->stream;
+    const int nslot = (int)slot_kind.size();
+    bool any_par = false, any_src = false, any_mos = false, any_gmin = false;
+    for (int i = 0; i < nslot; ++i) if (slot_set(i)) {
+      switch (slot_kind[i]) {
+        case CH_SLOT_DEV_PAR: if (dev[slot_a[i]].kind == CH_DEV_MOS) any_mos = true; else any_par = true; break;
+        case CH_SLOT_DEV_MULT: any_par = true; break;
+        case CH_SLOT_MODEL_PAR: case CH_SLOT_TEMP: any_mos = true; break;
+        case CH_SLOT_SRC_DC: case CH_SLOT_SRC_PAR: any_src = true; break;
+        case CH_SLOT_GMIN: any_gmin = true; break;
+      }
+    }
+    Spar = any_par ? S : 1; Ssrc = any_src ? S : 1; Smos = any_mos ? S : 1; Sgmin = any_gmin ? S : 1;
+    const int nh = (int)dev.size(), nsrc = (int)src.size();
+    // linear device parameters and multipliers
+    std::vector<double> hpar((size_t)nh * Spar), hmult((size_t)nh * Spar);
+    for (int d = 0; d < nh; ++d) for (int s = 0; s < Spar; ++s) { hpar[(size_t)d * Spar + s] = dev[d].par[0]; hmult[(size_t)d * Spar + s] = dev[d].mult; }
+    // sources
+    h_src_dc.assign((size_t)Ssrc * nsrc, 0.0); h_src_par.assign((size_t)Ssrc * nsrc * CH_SRC_NPAR, 0.0);
+    for (int s = 0; s < Ssrc; ++s) for (int i = 0; i < nsrc; ++i) { h_src_dc[(size_t)s * nsrc + i] = src[i].dc; for (int k = 0; k < CH_SRC_NPAR; ++k) h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR + k] = src[i].par[k]; }
+    std::vector<double> hg(Sgmin, gmin);
+    for (int i = 0; i < nslot; ++i) if (slot_set(i)) {
+      const int a = slot_a[i], b = slot_b[i];
+      for (int s = 0; s < S; ++s) {
+        const double v = slot_val[i][s];
+        switch (slot_kind[i]) {
+          case CH_SLOT_DEV_PAR: if (dev[a].kind != CH_DEV_MOS && b == 0) hpar[(size_t)a * Spar + s] = v; break;
+          case CH_SLOT_DEV_MULT: hmult[(size_t)a * Spar + s] = v; break;
+          case CH_SLOT_SRC_DC: h_src_dc[(size_t)s * nsrc + a] = v; if (src[a].kind == CH_SRC_DC) h_src_par[((size_t)s * nsrc + a) * CH_SRC_NPAR] = v; break;
+          case CH_SLOT_SRC_PAR: h_src_par[((size_t)s * nsrc + a) * CH_SRC_NPAR + b] = v; break;
+          case CH_SLOT_GMIN: hg[s] = v; break;
+          default: break;
+        }
+      }
+    }
+    HIPCHK(d_dpar.upload(hpar, st)); HIPCHK(d_dmult.upload(hmult, st)); HIPCHK(d_gmin.upload(hg, st));
+    // MOS classes: instances with identical (model, geometry, overriding slots) share a column
+    const int nmos = (int)A.mos_hdev.size();
+    mos_cls.assign(nmos, 0);
+    std::map<std::vector<double>, int> cls_of;
+    std::vector<int> cls_rep;
+    for (int m = 0; m < nmos; ++m) {
+      const HDev& d = dev[A.mos_hdev[m]];
+      std::vector<double> key;
+      key.push_back(d.ipar[0]);
+      for (int k = 0; k < 7; ++k) key.push_back(std::isnan(d.par[k]) ? -1e300 : d.par[k]);
+      for (int i = 0; i < nslot; ++i) if (slot_set(i) && slot_kind[i] == CH_SLOT_DEV_PAR && slot_a[i] == A.mos_hdev[m]) key.push_back(1e6 + i);
+      auto it = cls_of.find(key);
+      if (it == cls_of.end()) { it = cls_of.insert({key, (int)cls_rep.size()}).first; cls_rep.push_back(m); }
+      mos_cls[m] = it->second;
+    }
+    n_cls = (int)cls_rep.size();
+    const long cols = (long)std::max(1, n_cls) * Smos;
+    std::vector<double> table((size_t)B4I_COUNT * cols, 0.0), col(B4I_COUNT);
+    for (int c = 0; c < n_cls; ++c) {
+      const int hd = A.mos_hdev[cls_rep[c]];
+      for (int s = 0; s < Smos; ++s) {
+        std::vector<double> card = model[dev[hd].ipar[0]];
+        double ip[CH_DEV_NPAR]; for (int k = 0; k < CH_DEV_NPAR; ++k) ip[k] = dev[hd].par[k];
+        double tc = temp;
+        for (int i = 0; i < nslot; ++i) if (slot_set(i)) {
+          const double v = slot_val[i][Smos > 1 ? s : 0];
+          if (slot_kind[i] == CH_SLOT_MODEL_PAR && slot_a[i] == dev[hd].ipar[0]) card[slot_b[i]] = v;
+          else if (slot_kind[i] == CH_SLOT_DEV_PAR && slot_a[i] == hd) ip[slot_b[i]] = v;
+          else if (slot_kind[i] == CH_SLOT_TEMP) tc = v;
+        }
+        ip[CH_MOS_W] *= scale; ip[CH_MOS_L] *= scale;
+        int rc = b4_pack(card.data(), ip, tc, col.data());
+        if (rc != CH_OK) { set_err(rc == CH_ERR_UNSUPPORTED ? "BSIM4 card selects a sub-model the engine does not implement (rdsmod/rgatemod/rbodymod/igcmod/igbmod/trnqsmod/geomod != 0, diomod != 1, mobmod > 2, capmod not 0/2)" : "invalid MOS geometry or model card"); return rc; }
+        for (int k = 0; k < B4I_COUNT; ++k) table[(size_t)k * cols + (size_t)c * Smos + s] = col[k];
+      }
+    }
+    HIPCHK(d_mosp.upload(table, st));
+    std::vector<int> dcls;
+    for (const EDev& e : A.edev) dcls.push_back(e.mos >= 0 ? mos_cls[e.mos] : 0);
+    HIPCHK(d_dcls.upload(dcls, st));
+    HIPCHK(d_moscls_inst.upload(mos_cls, st));
+    // state ring and outputs
+    const size_t slot_elems = (size_t)S * A.n_unk;
+    HIPCHK(d_X.alloc(slot_elems * NSLOT)); HIPCHK(d_Q.alloc(slot_elems * NSLOT));
+    HIPCHK(hipMemsetAsync(d_X.p, 0, slot_elems * NSLOT * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(d_Q.p, 0, slot_elems * NSLOT * sizeof(double), st));
+    HIPCHK(d_out.alloc((size_t)A.n_comp * S));
+    HIPCHK(d_active.alloc((size_t)A.n_comp * S));
+    HIPCHK(d_kv.alloc((size_t)Ssrc * A.known.size())); HIPCHK(d_srcv.alloc((size_t)Ssrc * std::max(1, nsrc)));
+    const size_t need = (size_t)Ssrc * (A.known.size() + std::max(1, nsrc));
+    if (need > h_stage_n) { if (h_stage) (void)hipHostFree(h_stage); HIPCHK(hipHostMalloc((void**)&h_stage, need * sizeof(double))); h_stage_n = need; }
+    // argument template
+    NewtonArgs& a = base;
+    std::memset(&a, 0, sizeof(a));
+    a.comp_class = d_comp_class.p; a.comp_uofs = d_comp_uofs.p; a.comp_dofs = d_comp_dofs.p; a.classes = d_classes.p;
+    a.gl_ptr = d_gl_ptr.p; a.gl_src = d_gl_src.p; a.dkind = d_dkind.p; a.dterm = d_dterm.p; a.dsrc = d_dsrc.p; a.dcls = d_dcls.p; a.dhdev = d_dhdev.p;
+    a.dpar = d_dpar.p; a.dmult = d_dmult.p; a.mosp = d_mosp.p; a.mos_cols = cols; a.kv = d_kv.p; a.srcv = d_srcv.p; a.dmask = d_dmask.p;
+    a.active = nullptr; a.gmin_s = d_gmin.p;
+    a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = std::max(1, nsrc);
+    a.n_unk = A.n_unk; a.n_mos_cls = n_cls;
+    a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = d_out.p;
+    HIPCHK(hipStreamSynchronize(st));
+    dirty = false;
+    return CH_OK;
+  }
+
+  // host evaluation of source and known-node values for sample set s at time t
+  void eval_sources(double t, int mode, std::vector<double>& sv, std::vector<double>& kv) const {
+    const int nsrc = (int)src.size(), nk = (int)A.known.size();
+    sv.assign((size_t)Ssrc * std::max(1, nsrc), 0.0); kv.assign((size_t)Ssrc * nk, 0.0);
+    for (int s = 0; s < Ssrc; ++s) {
+      for (int i = 0; i < nsrc; ++i) sv[(size_t)s * std::max(1, nsrc) + i] = source_value(src[i], &h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR], h_src_dc[(size_t)s * nsrc + i], t, mode);
+      for (int k = 0; k < nk; ++k) { double v = 0; for (auto& tm : A.known[k].terms) v += tm.second * sv[(size_t)s * std::max(1, nsrc) + tm.first]; kv[(size_t)s * nk + k] = v; }
+    }
+  }
+  int upload_sources(double t, int mode) {
+    std::vector<double> sv, kv;
+    eval_sources(t, mode, sv, kv);
+    std::memcpy(h_stage, kv.data(), kv.size() * sizeof(double));
+    std::memcpy(h_stage + kv.size(), sv.data(), sv.size() * sizeof(double));
+    HIPCHK(hipMemcpyAsync(d_kv.p, h_stage, kv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_srcv.p, h_stage + kv.size(), sv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // the pinned staging buffer is reused next step: the stream sync at the end of the step protects it
+    return CH_OK;
+  }
+
+  // launch the fused Newton kernel + reduction and wait for the summary
+  int run_newton(const NewtonArgs& a, const unsigned char* active, Summary& out) {
+    hipStream_t st = ctx->stream;
+    const int nblk = A.n_comp * S;
+    HIPCHK(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(newton_block_kernel, dim3(nblk), dim3(64), lds_bytes, st, a);
+    HIPCHK(hipEventRecord(ev1, st));
+    hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 0, st, (const BlockOut*)d_out.p, A.n_comp, S, a.ck, a.ckm1, a.ckp1, active, d_sum.p);
+    HIPCHK(hipMemcpyAsync(h_sum, d_sum.p, sizeof(Summary), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    device_ms += ms; n_launch += 1;
+    out = *h_sum;
+    return CH_OK;
+  }
+
+  // unknown-space state of slot -> MNA vectors [S][n_mna]
+  int download_mna(int slot, double t, int mode, double* x_out) {
+    std::vector<double> xs((size_t)S * A.n_unk);
+    HIPCHK(hipMemcpy(xs.data(), d_X.p + (size_t)slot * S * A.n_unk, xs.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> sv, kv; eval_sources(t, mode, sv, kv);
+    const int nk = (int)A.known.size();
+    for (int s = 0; s < S; ++s) {
+      double* xo = x_out + (size_t)s * A.n_mna;
+      for (int n = 1; n <= n_nodes; ++n) xo[n - 1] = A.node_unknown[n] >= 0 ? xs[(size_t)s * A.n_unk + A.node_unknown[n]] : kv[(size_t)(Ssrc > 1 ? s : 0) * nk + A.node_known[n]];
+      for (int b = 0; b < A.n_branch; ++b) xo[n_nodes + b] = A.branch_unknown[b] >= 0 ? xs[(size_t)s * A.n_unk + A.branch_unknown[b]] : CH_NAN;
+    }
+    return CH_OK;
+  }
+  int upload_from_mna(int slot, const double* x_mna) {
+    std::vector<double> xs((size_t)S * A.n_unk);
+    for (int s = 0; s < S; ++s) for (int u = 0; u < A.n_unk; ++u) xs[(size_t)s * A.n_unk + u] = x_mna[(size_t)s * A.n_mna + A.unk_mna[u]];
+    HIPCHK(hipMemcpy(d_X.p + (size_t)slot * S * A.n_unk, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+    return CH_OK;
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // DC operating point: CedarDCOp + bootstrapped_nlsolve, restarted per block (src/dcop.jl:53-94).
+  // Leaves the solution in ring slot `slot`.
+  int dc_solve(const ch_dc_opts& o, int slot, std::vector<int>* status_out, ch_stats* stt) {
+    const int mode = o.tran_mode ? 2 : 0;
+    const int nblk = A.n_comp * S;
+    int rc = upload_sources(0.0, mode);
+    if (rc != CH_OK) return rc;
+    std::vector<unsigned char> active(nblk, 1);
+    std::vector<double> xs((size_t)S * A.n_unk), xm(A.n_mna);
+    std::vector<BlockOut> bo(nblk);
+    NewtonArgs a = base;
+    a.mode = MODE_DC; a.maxit = std::max(1, o.maxiters); a.dc_abstol = o.abstol; a.dv_max = o.dv_max; a.gshunt = 0.0;
+    a.abstol = 1e-6; a.reltol = 1e-3; a.newton_tol = 0.1;
+    a.hist_slot[0] = slot; a.cand_slot = slot; a.active = d_active.p;
+    std::vector<Rng> rngs; for (int s = 0; s < S; ++s) rngs.emplace_back(o.seed + (uint64_t)s);
+    auto block_of_unknown = [&](int u) { int c = (int)(std::upper_bound(A.comp_uofs.begin(), A.comp_uofs.end(), u) - A.comp_uofs.begin()) - 1; return c; };
+    int n_active = nblk;
+    const int nrest = std::max(1, o.n_restarts);
+    for (int r = 0; r < nrest + 1 && n_active > 0; ++r) {
+      const bool homotopy = (r == nrest);
+      // initial guess for the active blocks
+      HIPCHK(hipMemcpy(xs.data(), d_X.p + (size_t)slot * S * A.n_unk, xs.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int s = 0; s < S; ++s) {
+        bool any = false;
+        for (int c = 0; c < A.n_comp; ++c) if (active[(size_t)c * S + s]) any = true;
+        if (!any) continue;
+        if (!homotopy) {
+          if (r == 0 && o.x0) for (int i = 0; i < A.n_mna; ++i) xm[i] = o.x0[(size_t)s * A.n_mna + i];
+          else for (int i = 0; i < A.n_mna; ++i) xm[i] = 1e-7 * rngs[s].normal();
+        } else std::fill(xm.begin(), xm.end(), 0.0);
+        for (int u = 0; u < A.n_unk; ++u) if (active[(size_t)block_of_unknown(u) * S + s]) xs[(size_t)s * A.n_unk + u] = xm[A.unk_mna[u]];
+      }
+      HIPCHK(hipMemcpy(d_X.p + (size_t)slot * S * A.n_unk, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_active.p, active.data(), nblk, hipMemcpyHostToDevice));
+      Summary sm;
+      if (!homotopy) {
+        rc = run_newton(a, d_active.p, sm);
+        if (rc != CH_OK) return rc;
+      } else {
+        // gmin stepping: a shunt conductance on every node, relaxed decade by decade, then removed
+        for (double g = 1e-2; g >= 1e-13 * 0.99; g *= 0.1) { a.gshunt = g; rc = run_newton(a, d_active.p, sm); if (rc != CH_OK) return rc; }
+        a.gshunt = 0.0;
+        rc = run_newton(a, d_active.p, sm);
+        if (rc != CH_OK) return rc;
+      }
+      if (stt) { stt->nnonliniter += sm.sum_iters; stt->nf += sm.sum_iters; stt->njacs += sm.sum_iters; stt->nfactors += sm.sum_iters; stt->nsolve += sm.sum_iters; }
+      HIPCHK(hipMemcpy(bo.data(), d_out.p, nblk * sizeof(BlockOut), hipMemcpyDeviceToHost));
+      n_active = 0;
+      for (int b = 0; b < nblk; ++b) if (active[b]) { if (bo[b].status == 0) active[b] = 0; else ++n_active; }
+      if (n_active > 0 && stt) { stt->nrestarts++; stt->nnonlinconvfail++; }
+    }
+    if (status_out) { status_out->assign(S, CH_OK); for (int b = 0; b < nblk; ++b) if (active[b]) (*status_out)[b % S] = bo[b].status == 2 ? CH_ERR_SINGULAR : CH_ERR_MAXITERS; }
+    if (n_active > 0) { set_err("DC operating point analysis failed for " + std::to_string(n_active) + " block(s)"); return CH_ERR_MAXITERS; }
+    return CH_OK;
+  }
+
+  // ------------------------------------------------------------------------------------------
+  int tran_solve(double t0, double t1, const ch_tran_opts& o, ch_result& R) {
+    auto tstart = hclock::now();
+    std::memset(&R.stats, 0, sizeof(R.stats));
+    R.S = S; R.n_obs = (int)obs_kind.size();
+    device_ms = 0; n_launch = 0;
+    int rc = finalize_params();
+    if (rc != CH_OK) return rc;
+    hipStream_t st = ctx->stream;
+    const int kmax = std::min(5, std::max(1, o.max_order));
+    const double span = t1 - t0;
+    if (!(span > 0)) { set_err("tspan must be increasing"); return CH_ERR_INVALID; }
+    const double dtmax = o.dtmax > 0 ? o.dtmax : span / 10.0, dtmin = o.dtmin > 0 ? o.dtmin : 1e-15 * span;
+    const int max_steps = o.max_steps > 0 ? o.max_steps : 10000000, nmaxit = o.newton_maxiters > 0 ? o.newton_maxiters : 10;
+    const int n_obs = R.n_obs;
+
+    // ring bookkeeping: order[] lists slots newest-first
+    int order[NSLOT]; for (int i = 0; i < NSLOT; ++i) order[i] = i;
+    double htime[NSLOT] = {0};
+    int nhist = 1;
+    // ---- initialisation ----
+    if (o.skip_dc) {
+      if (o.dc.x0) { rc = upload_from_mna(order[0], o.dc.x0); if (rc != CH_OK) return rc; }
+      else HIPCHK(hipMemsetAsync(d_X.p + (size_t)order[0] * S * A.n_unk, 0, (size_t)S * A.n_unk * sizeof(double), st));
+    } else {
+      rc = dc_solve(o.dc, order[0], nullptr, &R.stats);
+      if (rc != CH_OK) return rc;
+    }
+    R.stats.dc_seconds = std::chrono::duration<double>(hclock::now() - tstart).count();
+    // charges at t0 in the problem's own mode
+    {
+      rc = upload_sources(t0, 1); if (rc != CH_OK) return rc;
+      NewtonArgs a = base; a.mode = MODE_EVAL; a.maxit = 1; a.hist_slot[0] = order[0]; a.cand_slot = order[0]; a.abstol = o.abstol; a.reltol = o.reltol;
+      Summary sm; rc = run_newton(a, nullptr, sm); if (rc != CH_OK) return rc;
+      R.stats.nf += S;
+    }
+    htime[0] = t0;
+
+    // break points of every sample's sources
+    std::vector<double> bps;
+    { const int nsrc = (int)src.size(); for (int s = 0; s < Ssrc; ++s) for (int i = 0; i < nsrc; ++i) source_breakpoints(src[i], &h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR], t0, t1, bps); }
+    bps.push_back(t1);
+    std::sort(bps.begin(), bps.end());
+    bps.erase(std::unique(bps.begin(), bps.end()), bps.end());
+    size_t ibp = 0;
+
+    // saved observables live on the device until the end
+    std::vector<double*> chunks; const int CH = 512; long nsaved = 0;
+    auto save = [&](double ts, const int* slots, const double* w, int nw) -> int {
+      if ((nsaved % CH) == 0) { double* p = nullptr; HIPCHK(hipMalloc((void**)&p, std::max<size_t>(1, (size_t)CH * n_obs * S) * sizeof(double))); chunks.push_back(p); }
+      if (n_obs > 0) {
+        ObsArgs oa; oa.X = d_X.p; oa.slot_stride = (long)S * A.n_unk; oa.nw = nw; oa.n_unk = A.n_unk; oa.S = S; oa.n_obs = n_obs; oa.obs_unk = d_obs_unk.p;
+        for (int j = 0; j < nw; ++j) { oa.slots[j] = slots[j]; oa.w[j] = w[j]; }
+        oa.dst = chunks.back() + (size_t)(nsaved % CH) * n_obs * S;
+        const int n = n_obs * S;
+        hipLaunchKernelGGL(save_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, oa);
+      }
+      R.times.push_back(ts); ++nsaved;
+      return CH_OK;
+    };
+    auto free_chunks = [&]() { for (double* p : chunks) (void)hipFree(p); chunks.clear(); };
+    int isave = 0;
+    { const double one = 1.0; const int s0 = order[0];
+      if (o.n_saveat == 0) { rc = save(t0, &s0, &one, 1); if (rc) { free_chunks(); return rc; } }
+      else while (isave < o.n_saveat && o.saveat[isave] <= t0) { rc = save(o.saveat[isave], &s0, &one, 1); if (rc) { free_chunks(); return rc; } ++isave; } }
+
+    const double kFirstFrac = 1e-3;
+    double t = t0;
+    double h = o.dt0 > 0 ? o.dt0 : std::min(dtmax, 1e-3 * span);
+    h = std::max(10 * dtmin, std::min(h, (bps[0] - t0) / 50.0) * kFirstFrac);
+    int k = 1, steps_at_order = 0, status = CH_OK;
+    double tau[9];
+    NewtonArgs a = base;
+    a.mode = MODE_TRAN; a.maxit = nmaxit; a.abstol = o.abstol; a.reltol = o.reltol; a.newton_tol = 0.1;
+
+    for (int step = 0; step < max_steps && t < t1;) {
+      while (ibp < bps.size() && bps[ibp] <= t * (1 + 1e-15) + 1e-300) ++ibp;
+      const double tb = ibp < bps.size() ? bps[ibp] : t1;
+      bool hit_bp = false;
+      double tn = t + h;
+      if (tn >= tb - 1e-3 * h) { tn = tb; hit_bp = true; }
+      const double hh = tn - t;
+      if (hh < dtmin) { status = CH_ERR_DTMIN; break; }
+      const int nh = nhist, kk = std::min(k, nh), np = std::min(kk + 1, nh);
+      tau[0] = tn; for (int j = 0; j < nh && j < 7; ++j) tau[j + 1] = htime[j];
+      extrap_weights(tau, np, a.wpred); a.npred = np;
+      bdf_coeffs(tau, kk, a.alpha); a.k = kk;
+      const bool lte = np >= kk + 1;
+      a.ck = lte ? hh / (tn - tau[kk + 1]) : 0.0;
+      a.nkm1 = 0; a.nkp1 = 0; a.ckm1 = 0; a.ckp1 = 0;
+      const bool try_up = lte && kk < kmax && nh >= kk + 2 && steps_at_order + 1 >= kk + 1;
+      if (lte && kk > 1) { extrap_weights(tau, kk, a.wkm1); a.nkm1 = kk; a.ckm1 = hh / (tn - tau[kk]); }
+      if (try_up) { extrap_weights(tau, kk + 2, a.wkp1); a.nkp1 = kk + 2; a.ckp1 = hh / (tn - tau[kk + 2]); }
+      for (int j = 0; j < 7; ++j) a.hist_slot[j] = order[std::min(j, nh - 1)];
+      a.cand_slot = order[NSLOT - 1];
+      rc = upload_sources(tn, 1); if (rc != CH_OK) { status = rc; break; }
+      Summary sm;
+      rc = run_newton(a, nullptr, sm); if (rc != CH_OK) { status = rc; break; }
+      R.stats.nnonliniter += sm.sum_iters; R.stats.nf += sm.sum_iters; R.stats.njacs += sm.sum_iters; R.stats.nfactors += sm.sum_iters; R.stats.nsolve += sm.sum_iters;
+      if (sm.n_fail > 0) {
+        R.stats.nnonlinconvfail++;
+        h = hh * 0.25; k = 1; steps_at_order = 0;
+        if (nhist > 2) nhist = 2;
+        continue;
+      }
+      const double errk = lte ? sm.errk : 0.0;
+      if (errk > 1.0) {
+        R.stats.nreject++;
+        const double fac = std::max(0.1, 0.9 * std::pow(errk, -1.0 / (kk + 1)));
+        h = hh * std::min(fac, 0.9);
+        steps_at_order = 0;
+        continue;
+      }
+      // ---- accept: candidate slot becomes the newest history point ----
+      R.stats.naccept++; ++step;
+      { int cand = order[NSLOT - 1]; for (int j = NSLOT - 1; j > 0; --j) { order[j] = order[j - 1]; htime[j] = htime[j - 1]; } order[0] = cand; htime[0] = tn; nhist = std::min(nhist + 1, kmax + 2); }
+      if (o.n_saveat > 0) {
+        while (isave < o.n_saveat && o.saveat[isave] <= tn * (1 + 1e-15)) {
+          const double ts = o.saveat[isave];
+          double tt[9], ww[9]; const int m = std::min(kk, nh) + 1;
+          tt[0] = ts; for (int j = 0; j < m; ++j) tt[j + 1] = htime[j];
+          extrap_weights(tt, m, ww);
+          rc = save(ts, order, ww + 1, m); if (rc) break;
+          ++isave;
+        }
+      } else { const double one = 1.0; rc = save(tn, order, &one, 1); }
+      if (rc != CH_OK) { status = rc; break; }
+      // ---- order / step selection ----
+      const double fac_k = 0.9 * std::pow(std::max(errk, 1e-10), -1.0 / (kk + 1));
+      double best = fac_k; int knew = kk;
+      if (lte) {
+        ++steps_at_order;
+        if (kk > 1) { const double f = 0.9 * std::pow(std::max(sm.errkm1, 1e-10), -1.0 / kk); if (f > best) { best = f; knew = kk - 1; } }
+        if (try_up) { const double f = 0.9 * std::pow(std::max(sm.errkp1, 1e-10), -1.0 / (kk + 2)); if (f > 1.1 * best) { best = f; knew = kk + 1; } }
+      } else knew = 1;
+      if (knew != kk) steps_at_order = 0;
+      k = knew;
+      h = std::min(dtmax, hh * std::min(kk == 1 ? 10.0 : 2.0, std::max(0.2, best)));
+      t = tn;
+      if (hit_bp && t < t1) {
+        nhist = 1; k = 1; steps_at_order = 0;
+        double nb = t1;
+        for (size_t b = ibp; b < bps.size(); ++b) if (bps[b] > t * (1 + 1e-15)) { nb = bps[b]; break; }
+        h = std::max(dtmin * 10, std::min(h, (nb - t) / 50.0) * kFirstFrac);
+      }
+    }
+    if (status == CH_OK && t < t1) status = CH_ERR_MAXSTEPS;
+    // ---- collect results ----
+    (void)hipStreamSynchronize(st);
+    const size_t nt = R.times.size();
+    R.values.assign((size_t)n_obs * nt * S, 0.0);
+    {
+      std::vector<double> buf((size_t)CH * n_obs * S);
+      for (size_t cidx = 0; cidx < chunks.size(); ++cidx) {
+        const size_t rows = std::min<size_t>(CH, nt - cidx * CH);
+        if (n_obs == 0 || rows == 0) continue;
+        (void)hipMemcpy(buf.data(), chunks[cidx], rows * n_obs * S * sizeof(double), hipMemcpyDeviceToHost);
+        for (size_t r = 0; r < rows; ++r) for (int ob = 0; ob < n_obs; ++ob)
+          std::memcpy(&R.values[((size_t)ob * nt + cidx * CH + r) * S], &buf[(r * n_obs + ob) * S], S * sizeof(double));
+      }
+      free_chunks();
+      // observables that are known nodes / ground are evaluated on the host
+      const int nk = (int)A.known.size();
+      std::vector<double> sv, kv;
+      for (int ob = 0; ob < n_obs; ++ob) {
+        if (obs_kind[ob] == 0 && A.node_unknown[obs_index[ob]] < 0) {
+          const int kn = A.node_known[obs_index[ob]];
+          for (size_t it = 0; it < nt; ++it) { eval_sources(R.times[it], 1, sv, kv); for (int s = 0; s < S; ++s) R.values[((size_t)ob * nt + it) * S + s] = kv[(size_t)(Ssrc > 1 ? s : 0) * nk + kn]; }
+        } else if (obs_kind[ob] == 1) {
+          const int b = dev[obs_index[ob]].branch;
+          if (b < 0 || A.branch_unknown[b] < 0) for (size_t it = 0; it < nt; ++it) for (int s = 0; s < S; ++s) R.values[((size_t)ob * nt + it) * S + s] = CH_NAN;
+        }
+      }
+    }
+    R.final_state.assign((size_t)S * A.n_mna, 0.0);
+    download_mna(order[0], t, 1, R.final_state.data());
+    R.status = status;
+    R.stats.wall_seconds = std::chrono::duration<double>(hclock::now() - tstart).count();
+    R.stats.device_seconds = device_ms * 1e-3;
+    R.stats.n_kernel_launches = n_launch;
+    if (status != CH_OK && err().empty()) set_err(status == CH_ERR_DTMIN ? "step size underflow (DtLessThanMin)" : "transient did not reach t1");
+    return status;
+  }
+};
+
+// =============================================================================================
+extern "C" {
+
+void ch_dc_opts_default(ch_dc_opts* o) { std::memset(o, 0, sizeof(*o)); o->abstol = 1e-10; o->maxiters = 200; o->n_restarts = 10; o->seed = 10; o->tran_mode = 0; o->dv_max = 2.0; o->x0 = nullptr; }
+void ch_tran_opts_default(ch_tran_opts* o) { std::memset(o, 0, sizeof(*o)); o->abstol = 1e-6; o->reltol = 1e-3; o->max_order = 5; o->newton_maxiters = 10; ch_dc_opts_default(&o->dc); }
+
+ch_ctx* ch_create(int device_id, char* err, size_t errlen) {
+  auto fail = [&](const std::string& m) -> ch_ctx* { if (err && errlen) { std::snprintf(err, errlen, "%s", m.c_str()); } return nullptr; };
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail(std::string("cedarhip needs a HIP device (gfx950); none available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
+  if (device_id < 0 || device_id >= n) return fail("invalid device id");
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(hipGetErrorString(e));
+  ch_ctx* c = new ch_ctx();
+  c->device = device_id;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail(hipGetErrorString(e)); }
+  return c;
+}
+void ch_destroy(ch_ctx* c) { if (!c) return; if (c->stream) (void)hipStreamDestroy(c->stream); delete c; }
+const char* ch_last_error(ch_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
+  if (!ctx || !d) return nullptr;
+  ctx->err.clear();
+  (void)hipSetDevice(ctx->device);
+  ch_circuit* c = new ch_circuit();
+  c->ctx = ctx;
+  c->n_nodes = d->n_nodes; c->temp = d->temp; c->gmin = d->gmin; c->scale = d->scale;
+  for (int i = 0; i < d->n_src; ++i) {
+    HSource s; s.kind = d->src_kind[i]; s.dc = d->src_dc[i];
+    for (int k = 0; k < CH_SRC_NPAR; ++k) s.par[k] = d->src_par[i * CH_SRC_NPAR + k];
+    if (d->src_pwl_ofs) for (int k = d->src_pwl_ofs[i]; k < d->src_pwl_ofs[i + 1]; ++k) { s.ts.push_back(d->pwl_t[k]); s.ys.push_back(d->pwl_y[k]); }
+    c->src.push_back(s);
+  }
+  for (int i = 0; i < d->n_model; ++i) c->model.emplace_back(d->model_par + (size_t)i * CH_B4_NPAR, d->model_par + (size_t)(i + 1) * CH_B4_NPAR);
+  auto bad = [&](const char* m) -> ch_circuit* { ctx->err = m; delete c; return nullptr; };
+  for (int i = 0; i < d->n_dev; ++i) {
+    HDev v; v.kind = d->dev_kind[i]; v.branch = -1; v.eliminated = false;
+    for (int k = 0; k < CH_DEV_NNODE; ++k) { v.node[k] = d->dev_node[i * CH_DEV_NNODE + k]; if (v.node[k] < 0 || v.node[k] > d->n_nodes) return bad("device node id out of range"); }
+    for (int k = 0; k < CH_DEV_NIPAR; ++k) v.ipar[k] = d->dev_ipar[i * CH_DEV_NIPAR + k];
+    for (int k = 0; k < CH_DEV_NPAR; ++k) v.par[k] = d->dev_par[i * CH_DEV_NPAR + k];
+    v.mult = d->dev_mult[i];
+    if (v.mult < 0) return bad("Cannot construct a ParallelInstances with non-positive multiplier");
+    if ((v.kind == CH_DEV_V || v.kind == CH_DEV_I) && (v.ipar[0] < 0 || v.ipar[0] >= d->n_src)) return bad("source index out of range");
+    if (v.kind == CH_DEV_MOS && (v.ipar[0] < 0 || v.ipar[0] >= d->n_model)) return bad("model index out of range");
+    if (v.kind < CH_DEV_R || v.kind > CH_DEV_MOS) return bad("unknown device kind");
+    c->dev.push_back(v);
+  }
+  for (int i = 0; i < d->n_slot; ++i) { c->slot_kind.push_back(d->slot_kind[i]); c->slot_a.push_back(d->slot_a[i]); c->slot_b.push_back(d->slot_b[i]); }
+  for (int i = 0; i < d->n_obs; ++i) { c->obs_kind.push_back(d->obs_kind[i]); c->obs_index.push_back(d->obs_index[i]); }
+  c->slot_val.assign(c->slot_kind.size(), {});
+  std::vector<char> protect(c->dev.size(), 0), swept(c->src.size(), 0);
+  for (size_t o = 0; o < c->obs_kind.size(); ++o) if (c->obs_kind[o] == 1) { if (c->obs_index[o] < 0 || c->obs_index[o] >= (int)c->dev.size()) return bad("observable device index out of range"); protect[c->obs_index[o]] = 1; }
+  for (size_t i = 0; i < c->slot_kind.size(); ++i) if (c->slot_kind[i] == CH_SLOT_SRC_DC || c->slot_kind[i] == CH_SLOT_SRC_PAR) swept[c->slot_a[i]] = 1;
+  int rc = analyse(c->n_nodes, c->dev, c->src, protect, swept, c->A);
+  if (rc != CH_OK) { ctx->err = c->A.err; delete c; return nullptr; }
+  rc = c->upload_structure();
+  if (rc != CH_OK) { delete c; return nullptr; }
+  return c;
+}
+void ch_circuit_free(ch_circuit* c) { delete c; }
+
+int ch_circuit_info(ch_circuit* c, ch_info* o) {
+  if (!c || !o) return CH_ERR_INVALID;
+  std::memset(o, 0, sizeof(*o));
+  const Analysis& A = c->A;
+  o->n_nodes = c->n_nodes; o->n_branches = A.n_branch; o->n_mna = A.n_mna; o->n_unknowns = A.n_unk; o->n_known = (int)A.known.size() - 1;
+  o->n_alias = A.n_alias; o->n_components = A.n_comp; o->max_component = A.max_nc; o->n_classes = (int)A.classes.size();
+  o->n_mos = (int)A.mos_hdev.size(); o->n_mos_classes = c->n_cls; o->path = 1; o->n_samples = c->S;
+  return CH_OK;
+}
+// maps for tests / host mirrors: MNA index -> unknown (or -1) for nodes 0..n_nodes and branches
+int ch_circuit_maps(ch_circuit* c, int32_t* node_unknown, int32_t* node_known, int32_t* branch_unknown) {
+  if (!c) return CH_ERR_INVALID;
+  for (int n = 0; n <= c->n_nodes; ++n) { if (node_unknown) node_unknown[n] = c->A.node_unknown[n]; if (node_known) node_known[n] = c->A.node_known[n]; }
+  for (int b = 0; b < c->A.n_branch; ++b) if (branch_unknown) branch_unknown[b] = c->A.branch_unknown[b];
+  return CH_OK;
+}
+
+int ch_set_samples(ch_circuit* c, int32_t n) {
+  if (!c || n < 1) return CH_ERR_INVALID;
+  c->S = n;
+  for (auto& v : c->slot_val) v.clear();
+  c->dirty = true;
+  return CH_OK;
+}
+int ch_set_params(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_slots, const int32_t* ids, const double* values) {
+  if (!c || lo < 0 || hi > c->S || lo >= hi) return CH_ERR_INVALID;
+  for (int i = 0; i < n_slots; ++i) {
+    const int id = ids[i];
+    if (id < 0 || id >= (int)c->slot_kind.size()) { c->set_err("slot id out of range"); return CH_ERR_INVALID; }
+    auto& v = c->slot_val[id];
+    if (v.empty()) {
+      // initialise with the description's base value
+      double base = 0; const int a = c->slot_a[id], b = c->slot_b[id];
+      switch (c->slot_kind[id]) {
+        case CH_SLOT_DEV_PAR: base = c->dev[a].par[b]; break;
+        case CH_SLOT_DEV_MULT: base = c->dev[a].mult; break;
+        case CH_SLOT_MODEL_PAR: base = c->model[a][b]; break;
+        case CH_SLOT_SRC_DC: base = c->src[a].dc; break;
+        case CH_SLOT_SRC_PAR: base = c->src[a].par[b]; break;
+        case CH_SLOT_TEMP: base = c->temp; break;
+        case CH_SLOT_GMIN: base = c->gmin; break;
+      }
+      v.assign(c->S, base);
+    }
+    for (int s = lo; s < hi; ++s) v[s] = values[(size_t)i * (hi - lo) + (s - lo)];
+  }
+  c->dirty = true;
+  return CH_OK;
+}
+
+int ch_dc(ch_circuit* c, const ch_dc_opts* o, double* x_out, int32_t* status_out, ch_stats* stats) {
+  if (!c || !o) return CH_ERR_INVALID;
+  c->ctx->err.clear();
+  (void)hipSetDevice(c->ctx->device);
+  auto t0 = hclock::now();
+  ch_stats st; std::memset(&st, 0, sizeof(st));
+  c->device_ms = 0; c->n_launch = 0;
+  int rc = c->finalize_params();
+  if (rc != CH_OK) return rc;
+  std::vector<int> status;
+  rc = c->dc_solve(*o, 0, &status, &st);
+  if (x_out) { int r2 = c->download_mna(0, 0.0, o->tran_mode ? 2 : 0, x_out); if (r2 != CH_OK) return r2; }
+  if (status_out) for (int s = 0; s < c->S; ++s) status_out[s] = status.empty() ? rc : status[s];
+  st.wall_seconds = st.dc_seconds = std::chrono::duration<double>(hclock::now() - t0).count();
+  st.device_seconds = c->device_ms * 1e-3; st.n_kernel_launches = c->n_launch;
+  if (stats) *stats = st;
+  return rc;
+}
+
+int ch_tran(ch_circuit* c, double t0, double t1, const ch_tran_opts* o, ch_result** out) {
+  if (!c || !o || !out) return CH_ERR_INVALID;
+  c->ctx->err.clear();
+  (void)hipSetDevice(c->ctx->device);
+  ch_result* R = new ch_result();
+  int rc = c->tran_solve(t0, t1, *o, *R);
+  R->status = rc;
+  *out = R;
+  return rc;
+}
+int64_t ch_result_n_times(const ch_result* r) { return r ? (int64_t)r->times.size() : 0; }
+const double* ch_result_times(const ch_result* r) { return r->times.data(); }
+const double* ch_result_values(const ch_result* r) { return r->values.data(); }
+const double* ch_result_final_state(const ch_result* r) { return r->final_state.data(); }
+int ch_result_stats(const ch_result* r, ch_stats* s) { if (!r || !s) return CH_ERR_INVALID; *s = r->stats; return CH_OK; }
+int ch_result_status(const ch_result* r) { return r ? r->status : CH_ERR_INVALID; }
+void ch_result_free(ch_result* r) { delete r; }
+
+int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double alpha0, int32_t mode, double* F_out, double* Q_out, double* J_out) {
+  if (!c || !x_mna || sample < 0 || sample >= c->S) return CH_ERR_INVALID;
+  c->ctx->err.clear();
+  (void)hipSetDevice(c->ctx->device);
+  int rc = c->finalize_params();
+  if (rc != CH_OK) return rc;
+  const Analysis& A = c->A;
+  const int S = c->S, nblk = A.n_comp * S, ds = A.max_nc;
+  // state: only the requested sample matters
+  std::vector<double> xs((size_t)S * A.n_unk, 0.0);
+  for (int u = 0; u < A.n_unk; ++u) xs[(size_t)sample * A.n_unk + u] = x_mna[A.unk_mna[u]];
+  if (hipMemcpy(c->d_X.p, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return CH_ERR_DEVICE;
+  std::vector<unsigned char> act(nblk, 0);
+  for (int k = 0; k < A.n_comp; ++k) act[(size_t)k * S + sample] = 1;
+  if (hipMemcpy(c->d_active.p, act.data(), nblk, hipMemcpyHostToDevice) != hipSuccess) return CH_ERR_DEVICE;
+  if (c->d_dumpA.alloc((size_t)nblk * ds * ds) != hipSuccess || c->d_dumpF.alloc((size_t)nblk * ds) != hipSuccess || c->d_dumpQ.alloc((size_t)nblk * ds) != hipSuccess) return CH_ERR_DEVICE;
+  rc = c->upload_sources(t, mode == 0 ? 0 : 1);
+  if (rc != CH_OK) return rc;
+  NewtonArgs a = c->base;
+  a.mode = MODE_EVAL; a.maxit = 1; a.alpha[0] = alpha0; a.hist_slot[0] = 0; a.cand_slot = 1; a.active = c->d_active.p; a.abstol = 1e-6; a.reltol = 1e-3;
+  a.dumpA = c->d_dumpA.p; a.dumpF = c->d_dumpF.p; a.dumpQ = c->d_dumpQ.p; a.dump_stride = ds;
+  Summary sm;
+  rc = c->run_newton(a, c->d_active.p, sm);
+  if (rc != CH_OK) return rc;
+  std::vector<double> hA((size_t)nblk * ds * ds), hF((size_t)nblk * ds), hQ((size_t)nblk * ds);
+  (void)hipMemcpy(hA.data(), c->d_dumpA.p, hA.size() * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hF.data(), c->d_dumpF.p, hF.size() * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hQ.data(), c->d_dumpQ.p, hQ.size() * sizeof(double), hipMemcpyDeviceToHost);
+  const int n = A.n_mna;
+  std::vector<char> has(n, 0);
+  if (J_out) std::fill(J_out, J_out + (size_t)n * n, 0.0);
+  if (F_out) std::fill(F_out, F_out + n, 0.0);
+  if (Q_out) std::fill(Q_out, Q_out + n, 0.0);
+  for (int k = 0; k < A.n_comp; ++k) {
+    const int blk = k * S + sample, nc = A.comp_nc[k], uo = A.comp_uofs[k];
+    for (int i = 0; i < nc; ++i) {
+      const int ri = A.unk_mna[uo + i];
+      has[ri] = 1;
+      if (F_out) F_out[ri] = hF[(size_t)blk * ds + i];
+      if (Q_out) Q_out[ri] = hQ[(size_t)blk * ds + i];
+      if (J_out) for (int j = 0; j < nc; ++j) J_out[(size_t)ri * n + A.unk_mna[uo + j]] = hA[(size_t)blk * ds * ds + (size_t)i * nc + j];
+    }
+  }
+  if (J_out) for (int i = 0; i < n; ++i) if (!has[i]) J_out[(size_t)i * n + i] = 1.0;
+  return CH_OK;
+}
+
+int ch_mos_eval(ch_circuit* c, int32_t sample, const double* v, double* out) {
+  if (!c || !v || !out || sample < 0 || sample >= c->S) return CH_ERR_INVALID;
+  c->ctx->err.clear();
+  (void)hipSetDevice(c->ctx->device);
+  int rc = c->finalize_params();
+  if (rc != CH_OK) return rc;
+  const int nm = (int)c->A.mos_hdev.size();
+  if (nm == 0) return CH_OK;
+  double *dv = nullptr, *dout = nullptr;
+  if (hipMalloc((void**)&dv, (size_t)nm * 4 * sizeof(double)) != hipSuccess || hipMalloc((void**)&dout, (size_t)nm * 40 * sizeof(double)) != hipSuccess) return CH_ERR_DEVICE;
+  (void)hipMemcpy(dv, v, (size_t)nm * 4 * sizeof(double), hipMemcpyHostToDevice);
+  std::vector<double> hg(c->Sgmin);
+  (void)hipMemcpy(hg.data(), c->d_gmin.p, hg.size() * sizeof(double), hipMemcpyDeviceToHost);
+  hipLaunchKernelGGL(mos_eval_kernel, dim3((nm + 63) / 64), dim3(64), 0, c->ctx->stream, (const double*)c->d_mosp.p, c->base.mos_cols, (const int*)c->d_moscls_inst.p, c->Smos, (int)sample, nm, (const double*)dv, hg[c->Sgmin > 1 ? sample : 0], dout);
+  hipError_t e = hipStreamSynchronize(c->ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)nm * 40 * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dv); (void)hipFree(dout);
+  if (e != hipSuccess) { c->set_err(hipGetErrorString(e)); return CH_ERR_DEVICE; }
+  return CH_OK;
+}
+
+static const char* const k_b4_names[] = {
+#define P(n, d) #n,
+#define B(n, d) #n, "l" #n, "w" #n, "p" #n,
+#define I(n)
+#include "../../include/cedarhip_bsim4_params.def"
+};
+static const char* const k_b4_ignored[] = {
+#define P(n, d)
+#define B(n, d)
+#define I(n) #n,
+#include "../../include/cedarhip_bsim4_params.def"
+    nullptr};
+int32_t ch_bsim4_npar(void) { return CH_B4_NPAR; }
+const char* ch_bsim4_param_name(int32_t i) { return (i >= 0 && i < CH_B4_NPAR) ? k_b4_names[i] : nullptr; }
+int32_t ch_bsim4_param_ignored(const char* name) {
+  if (!name) return 0;
+  for (int i = 0; k_b4_ignored[i]; ++i) if (std::strcmp(k_b4_ignored[i], name) == 0) return 1;
+  return 0;
+}
+const char* ch_version(void) { return "cedarhip 0.1 (gfx950; fused block Newton)"; }
+
+}  // extern "C"

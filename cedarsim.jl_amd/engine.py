@@ -1,0 +1,204 @@
+"""ctypes binding of libcedarhip.so — the C-ABI of include/cedarhip.h.
+
+The library is built in-tree (cedarsim.jl_amd/lib/libcedarhip.so) by `__graft_entry__.build()` or
+`make -C cedarsim.jl_amd/csrc`.  There is no CPU fallback: if the library is missing, or no HIP
+device is present, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .circuit import (ChDcOpts, ChDesc, ChInfo, ChStats, ChTranOpts, CedarError, RETCODES, dc_opts, tran_opts)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcedarhip.so")
+_pf64 = C.POINTER(C.c_double)
+_pi32 = C.POINTER(C.c_int32)
+
+EXPORTS = [
+    "ch_dc_opts_default", "ch_tran_opts_default", "ch_create", "ch_destroy", "ch_last_error", "ch_circuit_build",
+    "ch_circuit_free", "ch_circuit_info", "ch_circuit_maps", "ch_set_samples", "ch_set_params", "ch_dc", "ch_tran",
+    "ch_result_n_times", "ch_result_times", "ch_result_values", "ch_result_final_state", "ch_result_stats",
+    "ch_result_status", "ch_result_free", "ch_eval", "ch_mos_eval", "ch_bsim4_npar", "ch_bsim4_param_name",
+    "ch_bsim4_param_ignored", "ch_version",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libcedarhip.so and declare every prototype.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libcedarhip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C cedarsim.jl_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.ch_create.restype = vp
+    L.ch_create.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    L.ch_destroy.argtypes = [vp]
+    L.ch_last_error.restype = C.c_char_p
+    L.ch_last_error.argtypes = [vp]
+    L.ch_circuit_build.restype = vp
+    L.ch_circuit_build.argtypes = [vp, C.POINTER(ChDesc)]
+    L.ch_circuit_free.argtypes = [vp]
+    L.ch_circuit_info.argtypes = [vp, C.POINTER(ChInfo)]
+    L.ch_circuit_maps.argtypes = [vp, _pi32, _pi32, _pi32]
+    L.ch_set_samples.argtypes = [vp, C.c_int32]
+    L.ch_set_params.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, _pi32, _pf64]
+    L.ch_dc.argtypes = [vp, C.POINTER(ChDcOpts), _pf64, _pi32, C.POINTER(ChStats)]
+    L.ch_tran.argtypes = [vp, C.c_double, C.c_double, C.POINTER(ChTranOpts), C.POINTER(vp)]
+    L.ch_result_n_times.restype = C.c_int64
+    L.ch_result_n_times.argtypes = [vp]
+    for f in ("ch_result_times", "ch_result_values", "ch_result_final_state"):
+        getattr(L, f).restype = _pf64
+        getattr(L, f).argtypes = [vp]
+    L.ch_result_stats.argtypes = [vp, C.POINTER(ChStats)]
+    L.ch_result_status.argtypes = [vp]
+    L.ch_result_free.argtypes = [vp]
+    L.ch_eval.argtypes = [vp, C.c_int32, _pf64, C.c_double, C.c_double, C.c_int32, _pf64, _pf64, _pf64]
+    L.ch_mos_eval.argtypes = [vp, C.c_int32, _pf64, _pf64]
+    L.ch_bsim4_npar.restype = C.c_int32
+    L.ch_bsim4_param_name.restype = C.c_char_p
+    L.ch_bsim4_param_name.argtypes = [C.c_int32]
+    L.ch_bsim4_param_ignored.argtypes = [C.c_char_p]
+    L.ch_version.restype = C.c_char_p
+    L.ch_dc_opts_default.argtypes = [C.POINTER(ChDcOpts)]
+    L.ch_tran_opts_default.argtypes = [C.POINTER(ChTranOpts)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(_pf64)
+
+
+class Context:
+    """One per GPU (one process per GPU)."""
+
+    def __init__(self, device_id=0):
+        self.L = load_library()
+        buf = C.create_string_buffer(512)
+        self.h = self.L.ch_create(device_id, buf, 512)
+        if not self.h:
+            raise RuntimeError("ch_create failed: %s" % buf.value.decode())
+
+    def last_error(self):
+        return self.L.ch_last_error(self.h).decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ch_destroy(self.h)
+            self.h = None
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=None):
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("CEDARHIP_USE_LOCAL_RANK", "1") == "1" else 0
+        try:
+            import ctypes.util  # noqa: F401
+        except Exception:  # noqa: BLE001
+            pass
+    if device_id not in _default_ctx:
+        _default_ctx[device_id] = Context(device_id)
+    return _default_ctx[device_id]
+
+
+class EngineCircuit:
+    """A circuit resident on the GPU: structure analysed once, parameters per sample."""
+
+    def __init__(self, circuit, ctx=None):
+        self.ctx = ctx or default_context()
+        self.L = self.ctx.L
+        self.circuit = circuit
+        self._desc = circuit.to_desc()
+        self.h = self.L.ch_circuit_build(self.ctx.h, C.byref(self._desc))
+        if not self.h:
+            raise CedarError("ch_circuit_build failed: %s" % self.ctx.last_error())
+        self.n_mna = circuit.n_mna
+        self.n_samples = 1
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.ch_circuit_free(self.h)
+        except Exception:  # noqa: BLE001
+            pass
+
+    def info(self):
+        i = ChInfo()
+        self.L.ch_circuit_info(self.h, C.byref(i))
+        return i.asdict()
+
+    def maps(self):
+        nn, nb = self.circuit.n_nodes, len(self.circuit.branch_devices)
+        nu = np.zeros(nn + 1, np.int32)
+        nk = np.zeros(nn + 1, np.int32)
+        bu = np.zeros(max(1, nb), np.int32)
+        self.L.ch_circuit_maps(self.h, nu.ctypes.data_as(_pi32), nk.ctypes.data_as(_pi32), bu.ctypes.data_as(_pi32))
+        return nu, nk, bu[:nb]
+
+    def _check(self, rc, what):
+        if rc not in (0,):
+            raise CedarError("%s failed (%s): %s" % (what, RETCODES.get(rc, rc), self.ctx.last_error()))
+
+    def set_samples(self, n):
+        self._check(self.L.ch_set_samples(self.h, int(n)), "ch_set_samples")
+        self.n_samples = int(n)
+
+    def set_params(self, slot_ids, values, lo=0, hi=None):
+        """values[slot][sample] for samples lo..hi."""
+        hi = self.n_samples if hi is None else hi
+        ids = np.ascontiguousarray(slot_ids, dtype=np.int32)
+        vals = np.ascontiguousarray(values, dtype=np.float64).reshape(len(ids), hi - lo)
+        self._check(self.L.ch_set_params(self.h, lo, hi, len(ids), ids.ctypes.data_as(_pi32), _p(vals)), "ch_set_params")
+
+    def dc(self, opts=None, check=False):
+        opts = opts or dc_opts()
+        x = np.zeros((self.n_samples, self.n_mna))
+        status = np.zeros(self.n_samples, np.int32)
+        st = ChStats()
+        rc = self.L.ch_dc(self.h, C.byref(opts), _p(x), status.ctypes.data_as(_pi32), C.byref(st))
+        if check:
+            self._check(rc, "ch_dc")
+        return rc, x, status, st.asdict()
+
+    def tran(self, t0, t1, opts=None):
+        opts = opts or tran_opts()
+        r = C.c_void_p()
+        rc = self.L.ch_tran(self.h, float(t0), float(t1), C.byref(opts), C.byref(r))
+        if not r:
+            raise CedarError("ch_tran failed: %s" % self.ctx.last_error())
+        try:
+            nt = self.L.ch_result_n_times(r)
+            nobs = len(self.circuit.obs)
+            S = self.n_samples
+            t = np.ctypeslib.as_array(self.L.ch_result_times(r), (nt,)).copy() if nt else np.zeros(0)
+            v = np.ctypeslib.as_array(self.L.ch_result_values(r), (nobs, nt, S)).copy() if nt and nobs else np.zeros((nobs, nt, S))
+            fs = self.L.ch_result_final_state(r)
+            xf = np.ctypeslib.as_array(fs, (S, self.n_mna)).copy() if fs and nt else np.zeros((S, self.n_mna))
+            st = ChStats()
+            self.L.ch_result_stats(r, C.byref(st))
+            return rc, t, v, xf, st.asdict()
+        finally:
+            self.L.ch_result_free(r)
+
+    def eval(self, x_mna, t=0.0, alpha0=0.0, mode=1, sample=0):
+        x = np.ascontiguousarray(x_mna, dtype=np.float64)
+        n = self.n_mna
+        F, Q, J = np.zeros(n), np.zeros(n), np.zeros((n, n))
+        self._check(self.L.ch_eval(self.h, sample, _p(x), t, alpha0, mode, _p(F), _p(Q), _p(J)), "ch_eval")
+        return F, Q, J
+
+    def mos_eval(self, v, sample=0):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        nm = self.info()["n_mos"]
+        out = np.zeros((nm, 40))
+        self._check(self.L.ch_mos_eval(self.h, sample, _p(v), _p(out)), "ch_mos_eval")
+        return out

@@ -202,6 +202,10 @@ const char* ch_last_error(ch_ctx*);
 ch_circuit* ch_circuit_build(ch_ctx*, const ch_desc*);
 void ch_circuit_free(ch_circuit*);
 int ch_circuit_info(ch_circuit*, ch_info*);
+/* Result of the structural analysis, for host mirrors and tests: for node 0..n_nodes the index of
+ * the unknown that carries its voltage (or -1) and of the known value (or -1); for each MNA branch
+ * the unknown of its current (or -1 when the source was eliminated). */
+int ch_circuit_maps(ch_circuit*, int32_t* node_unknown, int32_t* node_known, int32_t* branch_unknown);
 
 /* ---- samples: replaces remake(prob, p=sim) over the sweep (src/sweeps.jl:471-482). ----
  * values is slot-major: values[slot_i * (sample_hi-sample_lo) + (s - sample_lo)]. */
