@@ -1,0 +1,287 @@
+"""User-facing analyses — host-side mirror of CedarSim's problem surface for the hot path.
+
+    dc(circuit; abstol…)                ≙ dc!(circ)                 src/sweeps.jl:437-448
+    tran(circuit, tspan; abstol, reltol) ≙ tran!(circ, tspan)        src/sweeps.jl:450-465
+    CircuitSweep(builder, sweep)         ≙ CircuitSweep(circuit, sweep)  src/sweeps.jl:390-435
+    dc(cs) / tran(cs, tspan)             ≙ dc!(cs) / tran!.(…) broadcast  src/sweeps.jl:448,471-502
+    sol.retcode, sol.t, sol["node_q"], sol["r.i"], sol(t, idxs=…), sol.stats   SURVEY §8(b)
+
+The reference loops serially over sweep points, paying a full DC + transient each
+(`broadcast(sims) do sim … remake(prob, p=sim)`, src/sweeps.jl:473-480).  Here every point becomes one
+*sample* of a single batched GPU solve (`ch_set_params` + one `ch_dc`/`ch_tran`); with several ranks
+the points are split into contiguous shards, one per GPU, and results are gathered at the end.
+All numerics run in libcedarhip.so; nothing here computes a circuit solution.
+"""
+import math
+
+import numpy as np
+
+from .circuit import (DEV_C, DEV_L, DEV_MOS, DEV_R, DEV_V, DEV_VCVS, RETCODES, CedarError, Circuit, dc_opts, tran_opts)
+from .engine import EngineCircuit
+from .sweeps import shard_range, sweepify
+
+
+class Solution:
+    """Solution of one sample: time points, observables by name, retcode and stats."""
+
+    def __init__(self, circuit, t, cols, x_final, rc, stats, params=None):
+        self.circuit, self.t, self._cols, self.x_final = circuit, np.asarray(t), cols, x_final
+        self.retcode = RETCODES.get(rc, str(rc))
+        self.rc = rc
+        self.stats = stats
+        self.params = params or {}
+
+    # -- symbolic indexing: "node_q" / "q" (node voltage), "r1.i" / "r1.v" (device current / voltage) --
+    def _node_series(self, node):
+        c = self.circuit
+        n = c._n(node) if not isinstance(node, (int, np.integer)) else int(node)
+        if n == 0:
+            return np.zeros(len(self.t))
+        key = ("v", n)
+        if key in self._cols:
+            return self._cols[key]
+        if len(self.t) == 1 and self.x_final is not None:
+            return np.array([self.x_final[n - 1]])
+        raise KeyError("node '%s' was not observed" % node)
+
+    def __getitem__(self, name):
+        c = self.circuit
+        nm = str(name).lower()
+        if nm.startswith("node_"):
+            nm = nm[5:]
+        if nm in c._node_ix:
+            return self._node_series(nm)
+        if "." in nm:
+            dev, fld = nm.rsplit(".", 1)
+            if dev in c.dev_names and fld in ("i", "v"):
+                i = c.dev_names.index(dev)
+                a, b = c.dev_node[i][0], c.dev_node[i][1]
+                v = self._node_series(a) - self._node_series(b)
+                if fld == "v":
+                    return v
+                k = c.dev_kind[i]
+                if k == DEV_R:
+                    return v / c.dev_par[i][0]
+                if k in (DEV_V, DEV_L, DEV_VCVS):
+                    key = ("i", i)
+                    if key in self._cols:
+                        return self._cols[key]
+                    if len(self.t) == 1 and self.x_final is not None:
+                        return np.array([self.x_final[c.mna_index("i", dev)]])
+                    raise KeyError("branch current of '%s' was not observed" % dev)
+                if k == DEV_C:
+                    if len(self.t) < 2:
+                        return np.zeros(len(self.t))
+                    return c.dev_par[i][0] * np.gradient(v, self.t)  # post-processed derivative
+        raise KeyError(name)
+
+    def __call__(self, t, idxs=None):
+        """Interpolated observables (linear between saved points; pass `saveat` for exact times)."""
+        names = idxs if isinstance(idxs, (list, tuple)) else [idxs]
+        out = [np.interp(t, self.t, self[n]) for n in names]
+        return out if isinstance(idxs, (list, tuple)) else out[0]
+
+
+def _prepare(circuit, observe):
+    if isinstance(circuit, Circuit):
+        ckt = circuit
+    elif hasattr(circuit, "build"):
+        ckt = circuit.build()
+    else:
+        raise CedarError("expected a Circuit or a parsed netlist")
+    if observe is None and not ckt.obs:
+        ckt.observe_all_nodes()
+        for i, k in enumerate(ckt.dev_kind):
+            if k in (DEV_V, DEV_L, DEV_VCVS):
+                ckt.observe_branch(ckt.dev_names[i])
+    elif observe:
+        for o in observe:
+            o = str(o).lower()
+            if o.endswith(".i") and o[:-2] in ckt.dev_names:
+                ckt.observe_branch(o[:-2])
+            else:
+                ckt.observe_node(o[5:] if o.startswith("node_") else o)
+    return ckt
+
+
+def _solutions(ckt, t, v, xf, rc, status, st, S, point_params=None):
+    sols = []
+    for s in range(S):
+        cols = {}
+        for k, o in enumerate(ckt.obs):
+            cols[o] = v[k, :, s] if v.size else np.zeros(0)
+        sols.append(Solution(ckt, t, cols, xf[s] if xf is not None else None, int(status[s]) if status is not None else rc, st,
+                             point_params[s] if point_params else None))
+    return sols
+
+
+def dc(circuit, abstol=1e-10, maxiters=200, n_restarts=10, seed=10, tran_mode=False, u0=None, observe=None, ctx=None):
+    """DC operating point (CedarDCOp: sources at their .dc value, du = 0; src/dcop.jl:157-200)."""
+    if isinstance(circuit, CircuitSweep):
+        return circuit._run("dc", dict(abstol=abstol, maxiters=maxiters, n_restarts=n_restarts, seed=seed, tran_mode=tran_mode), ctx)
+    ckt = _prepare(circuit, observe)
+    eng = EngineCircuit(ckt, ctx)
+    rc, x, status, st = eng.dc(dc_opts(abstol=abstol, maxiters=maxiters, n_restarts=n_restarts, seed=seed, tran_mode=tran_mode, x0=u0))
+    if rc != 0:
+        import warnings
+        warnings.warn("DC operating point analysis failed. Further failures may follow.")  # src/dcop.jl:141
+    cols = {}
+    for o in ckt.obs:
+        idx = (o[1] - 1) if o[0] == "v" else ckt.mna_index("i", ckt.dev_names[o[1]])
+        cols[o] = np.array([x[0][idx]])
+    return Solution(ckt, np.array([0.0]), cols, x[0], rc, st)
+
+
+def tran(circuit, tspan=None, abstol=1e-6, reltol=1e-3, u0=None, initializealg="dcop", dc_abstol=1e-10, saveat=None,
+         max_order=5, observe=None, ctx=None, **kw):
+    """Transient (solve(prob, IDA(); abstol, reltol, initializealg=CedarDCOp()), src/sweeps.jl:450-465).
+
+    u0: MNA initial state → skips the DC solve (test/common.jl:36-43 `u0=` semantics).
+    tspan defaults to the netlist's `.TRAN` (src/circsummary.jl:109-128)."""
+    if isinstance(circuit, CircuitSweep):
+        return circuit._run("tran", dict(tspan=tspan, abstol=abstol, reltol=reltol, initializealg=initializealg, dc_abstol=dc_abstol,
+                                          saveat=saveat, max_order=max_order, **kw), ctx)
+    if tspan is None:
+        nl = circuit if hasattr(circuit, "tran") and not isinstance(circuit, Circuit) else getattr(circuit, "_netlist", None)
+        if nl is None or nl.tran is None:
+            raise CedarError("no tspan given and the netlist has no .TRAN statement")
+        tspan = (0.0, nl.tran[1])
+    ckt = _prepare(circuit, observe)
+    eng = EngineCircuit(ckt, ctx)
+    dco = dc_opts(abstol=dc_abstol, tran_mode=(initializealg == "tranop"), x0=None if u0 is None else np.asarray(u0, float)[None, :])
+    opts = tran_opts(abstol=abstol, reltol=reltol, max_order=max_order, saveat=saveat, dc=dco, skip_dc=u0 is not None, **kw)
+    rc, t, v, xf, st = eng.tran(tspan[0], tspan[1], opts)
+    return _solutions(ckt, t, v, xf, rc, None, st, 1)[0]
+
+
+class CircuitSweep:
+    """Batched sweep over circuit parameters (src/sweeps.jl:390-435).
+
+    builder: a parsed netlist (`.build(**params)`) or a callable `f(**params) -> Circuit`.
+    Iterating yields one parameter dict per point (`s.params` in the reference)."""
+
+    def __init__(self, builder, sweep, rank=0, world=1):
+        self.builder = builder
+        self.sweep = sweepify(sweep)
+        self.points = [{k: v for k, v in p if v is not None} for p in self.sweep]
+        self.shape = self.sweep.shape
+        self.rank, self.world = rank, world
+        self._build = builder.build if hasattr(builder, "build") else builder
+
+    def __iter__(self):
+        return iter(self.points)
+
+    def __len__(self):
+        return len(self.points)
+
+    def _batch(self, lo, hi):
+        """Base circuit + slots + per-sample values for points lo..hi (found by diffing flat tables)."""
+        base = self._build(**self.points[lo])
+        circuits = [base] + [self._build(**p) for p in self.points[lo + 1:hi]]
+        for c in circuits[1:]:
+            if c.dev_kind != base.dev_kind or c.dev_node != base.dev_node or c.dev_ipar != base.dev_ipar:
+                raise CedarError("sweep points must not change the circuit topology")
+        slots, values = [], []
+
+        def add(slot, vals):
+            slots.append(slot)
+            values.append(vals)
+
+        from .circuit import (SLOT_DEV_MULT, SLOT_DEV_PAR, SLOT_GMIN, SLOT_MODEL_PAR, SLOT_SRC_DC, SLOT_SRC_PAR, SLOT_TEMP)
+        par = np.array([c.dev_par for c in circuits], float)          # [P][ndev][8]
+        mult = np.array([c.dev_mult for c in circuits], float)
+        differs = lambda a: np.any((a != a[0]) & ~(np.isnan(a) & np.isnan(a[0])), axis=0)
+        if par.size:
+            dm = differs(par)
+            for d, k in zip(*np.nonzero(dm)):
+                add((SLOT_DEV_PAR, int(d), int(k)), par[:, d, k])
+            for d in np.nonzero(differs(mult))[0]:
+                add((SLOT_DEV_MULT, int(d), 0), mult[:, d])
+        sdc = np.array([[s[0] for s in c.sources] for c in circuits], float)
+        spar = np.array([[list(s[1].par) + [0.0] * (8 - len(s[1].par)) for s in c.sources] for c in circuits], float)
+        if sdc.size:
+            for i in np.nonzero(differs(sdc))[0]:
+                add((SLOT_SRC_DC, int(i), 0), sdc[:, i])
+            for i, k in zip(*np.nonzero(differs(spar))):
+                if base.sources[i][1].kind == 0 and k == 0 and any(s[0] == SLOT_SRC_DC and s[1] == i for s in slots):
+                    continue  # constant source: SRC_DC already updates the transient value
+                add((SLOT_SRC_PAR, int(i), int(k)), spar[:, i, k])
+        mods = np.array([c.models for c in circuits], float)
+        if mods.size:
+            for m, k in zip(*np.nonzero(differs(mods))):
+                add((SLOT_MODEL_PAR, int(m), int(k)), mods[:, m, k])
+        temps = np.array([c.temp for c in circuits])
+        if np.any(temps != temps[0]):
+            add((SLOT_TEMP, 0, 0), temps)
+        gm = np.array([c.gmin for c in circuits])
+        if np.any(gm != gm[0]):
+            add((SLOT_GMIN, 0, 0), gm)
+        base.slots = list(slots)
+        base.slot_names = [("slot%d" % i, None) for i in range(len(slots))]
+        return base, list(range(len(slots))), np.array(values, float).reshape(len(slots), hi - lo)
+
+    def _run(self, kind, kw, ctx):
+        lo, hi = shard_range(len(self.points), self.rank, self.world)
+        if hi <= lo:
+            return []
+        base, slot_ids, vals = self._batch(lo, hi)
+        ckt = _prepare(base, None)
+        eng = EngineCircuit(ckt, ctx)
+        S = hi - lo
+        eng.set_samples(S)
+        if slot_ids:
+            eng.set_params(slot_ids, vals)
+        pts = self.points[lo:hi]
+        if kind == "dc":
+            rc, x, status, st = eng.dc(dc_opts(**kw))
+            sols = []
+            for s in range(S):
+                cols = {}
+                for o in ckt.obs:
+                    idx = (o[1] - 1) if o[0] == "v" else ckt.mna_index("i", ckt.dev_names[o[1]])
+                    cols[o] = np.array([x[s][idx]])
+                ck = self._sample_circuit(ckt, slot_ids, vals, s)
+                sols.append(Solution(ck, np.array([0.0]), cols, x[s], int(status[s]), st, pts[s]))
+            return sols
+        tspan = kw.pop("tspan")
+        dco = dc_opts(abstol=kw.pop("dc_abstol", 1e-10), tran_mode=(kw.pop("initializealg", "dcop") == "tranop"))
+        opts = tran_opts(dc=dco, **kw)
+        rc, t, v, xf, st = eng.tran(tspan[0], tspan[1], opts)
+        sols = _solutions(ckt, t, v, xf, rc, None, st, S, pts)
+        for s, sol in enumerate(sols):
+            sol.circuit = self._sample_circuit(ckt, slot_ids, vals, s)
+        return sols
+
+    @staticmethod
+    def _sample_circuit(ckt, slot_ids, vals, s):
+        """Shallow per-sample view so that post-processing (e.g. R.I = V/r) uses the sample's values."""
+        import copy
+        from .circuit import SLOT_DEV_PAR
+        c = copy.copy(ckt)
+        c.dev_par = [list(p) for p in ckt.dev_par]
+        for i, sl in enumerate(ckt.slots):
+            if sl[0] == SLOT_DEV_PAR:
+                c.dev_par[sl[1]][sl[2]] = float(vals[i][s])
+        return c
+
+
+def gather_sharded(local, n_total, rank, world, group=None, device=None):
+    """All-gather per-rank result rows (one collective at the end, none in the Newton
+    loop).  `local` is a float64 array [n_local, ...] for this rank's contiguous shard; returns the
+    full [n_total, ...] array on every rank.  Backend nccl (= RCCL over xGMI) needs `device='cuda'`."""
+    import torch
+    import torch.distributed as dist
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    tail = local.shape[1:]
+    width = int(np.prod(tail)) if tail else 1
+    max_rows = -(-n_total // world)
+    buf = torch.zeros((max_rows, width), dtype=torch.float64, device=device or "cpu")
+    if local.shape[0]:
+        buf[:local.shape[0]] = torch.from_numpy(local.reshape(local.shape[0], width)).to(buf.device)
+    out = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        rows.append(out[r][:hi - lo].cpu().numpy())
+    return np.concatenate(rows, axis=0).reshape((n_total,) + tuple(tail))

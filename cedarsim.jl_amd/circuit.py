@@ -50,7 +50,7 @@ class ChStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("nf", "njacs", "nfactors", "nsolve", "nnonliniter", "nnonlinconvfail",
                                          "naccept", "nreject", "nrestarts")] + \
                [("wall_seconds", C.c_double), ("dc_seconds", C.c_double), ("device_seconds", C.c_double),
-                ("n_kernel_launches", C.c_int64)]
+                ("n_kernel_launches", C.c_int64), ("n_block_iters", C.c_int64)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

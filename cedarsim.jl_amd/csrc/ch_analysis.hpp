@@ -60,6 +60,7 @@ struct EDev {
 
 struct CompClass {
   int nc = 0, ndev = 0;
+  bool nonlinear = false;                  // contains a MOSFET: DC Newton steps are voltage-limited
   std::vector<int> mat_ptr, vec_ptr;       // CSR over nc*nc matrix targets / nc vector targets
   std::vector<uint16_t> mat_src, vec_src;  // staging offsets dev_local*40 + slot (G block / F block)
 };
@@ -286,6 +287,7 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
       const EDev& e = A.edev[A.comp_dofs[c] + i];
       bool vm[4], mm[16];
       kind_mask(e.kind, vm, mm);
+      if (e.kind == K_MOS) cl.nonlinear = true;
       int row[4];
       for (int k = 0; k < 4; ++k) row[k] = e.term[k] >= 0 ? e.term[k] - A.comp_uofs[c] : -1;
       for (int k = 0; k < 4; ++k) if (vm[k] && row[k] >= 0) vl[row[k]].push_back((uint16_t)(i * 40 + k));

@@ -93,8 +93,18 @@ void source_breakpoints(const HSource& s, const double* par, double t0, double t
     const double td = par[2], tr = par[3], tf = par[4], pw = par[5], per = par[6];
     const double c[4] = {td, td + tr, td + tr + pw, td + tr + pw + tf};
     if (!std::isfinite(per) || per <= 0) { for (double t : c) if (t > t0 && t < t1) out.push_back(t); }
-    else { long k0 = std::max(0L, (long)std::floor(t0 / per) - 1); for (long k = k0; k * per < t1 && (k - k0) < 10000000; ++k) for (double tc : c) { double t = tc + k * per; if (t > t0 && t < t1) out.push_back(t); } }
-  } else if (s.kind == CH_SRC_SIN) { if (par[3] > t0 && par[3] < t1) out.push_back(par[3]); }
+    else {
+      long k0 = std::max(0L, (long)std::floor(t0 / per) - 1);
+      for (long k = k0; k * per < t1 && (k - k0) < 10000000; ++k) {
+        for (double tc : c) { double t = tc + k * per; if (t > t0 && t < t1) out.push_back(t); }
+        if (k >= 1 && k * per > t0 && k * per < t1) out.push_back(k * per);  // wrap of `t mod period` may jump
+      }
+    }
+  } else if (s.kind == CH_SRC_SIN) {
+    const double te = par[6] / par[2];
+    if (par[3] > t0 && par[3] < t1) out.push_back(par[3]);
+    if (std::isfinite(te) && te > t0 && te < t1) out.push_back(te);
+  }
 }
 
 // variable-coefficient BDF helpers: tau[0] = t_new, tau[1..] history (newest first)
@@ -162,7 +172,7 @@ struct ch_circuit {
   DevBuf<int> d_comp_class, d_comp_uofs, d_comp_dofs, d_gl_ptr, d_dkind, d_dterm, d_dsrc, d_dcls, d_dhdev, d_obs_unk, d_moscls_inst;
   DevBuf<ClassMeta> d_classes;
   DevBuf<uint16_t> d_gl_src;
-  DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ;
+  DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ;  // (d_srcv unused: source values share d_kv)
   DevBuf<unsigned char> d_dmask, d_active;
   DevBuf<BlockOut> d_out;
   DevBuf<Summary> d_sum;
@@ -190,7 +200,7 @@ struct ch_circuit {
     hipStream_t st = ctx->stream;
     std::vector<ClassMeta> cms; std::vector<int> ptr; std::vector<uint16_t> srcs;
     for (const CompClass& c : A.classes) {
-      ClassMeta m; m.nc = c.nc; m.ndev = c.ndev;
+      ClassMeta m; m.nc = c.nc; m.ndev = c.ndev; m.nonlinear = c.nonlinear ? 1 : 0; m.pad = 0;
       m.mat_ptr_ofs = (int)ptr.size(); ptr.insert(ptr.end(), c.mat_ptr.begin(), c.mat_ptr.end());
       m.vec_ptr_ofs = (int)ptr.size(); ptr.insert(ptr.end(), c.vec_ptr.begin(), c.vec_ptr.end());
       m.mat_src_ofs = (int)srcs.size(); srcs.insert(srcs.end(), c.mat_src.begin(), c.mat_src.end());
@@ -213,7 +223,7 @@ struct ch_circuit {
     HIPCHK(d_dkind.upload(dkind, st)); HIPCHK(d_dterm.upload(dterm, st)); HIPCHK(d_dsrc.upload(dsrc, st)); HIPCHK(d_dhdev.upload(dhdev, st));
     HIPCHK(d_dmask.upload(dm, st)); HIPCHK(d_obs_unk.upload(obs_unk, st));
     HIPCHK(d_sum.alloc(1));
-    HIPCHK(hipHostMalloc((void**)&h_sum, sizeof(Summary)));
+    HIPCHK(hipHostMalloc((void**)&h_sum, sizeof(Summary), hipHostMallocMapped));
     HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
     size_t ld = 0;
     for (const CompClass& c : A.classes) ld = std::max(ld, (size_t)c.ndev * 40 + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 8 * (size_t)c.nc);
@@ -314,15 +324,15 @@ struct ch_circuit {
     HIPCHK(hipMemsetAsync(d_Q.p, 0, slot_elems * NSLOT * sizeof(double), st));
     HIPCHK(d_out.alloc((size_t)A.n_comp * S));
     HIPCHK(d_active.alloc((size_t)A.n_comp * S));
-    HIPCHK(d_kv.alloc((size_t)Ssrc * A.known.size())); HIPCHK(d_srcv.alloc((size_t)Ssrc * std::max(1, nsrc)));
     const size_t need = (size_t)Ssrc * (A.known.size() + std::max(1, nsrc));
+    HIPCHK(d_kv.alloc(need));  // [kv | srcv] contiguous: one upload per step
     if (need > h_stage_n) { if (h_stage) (void)hipHostFree(h_stage); HIPCHK(hipHostMalloc((void**)&h_stage, need * sizeof(double))); h_stage_n = need; }
     // argument template
     NewtonArgs& a = base;
     std::memset(&a, 0, sizeof(a));
     a.comp_class = d_comp_class.p; a.comp_uofs = d_comp_uofs.p; a.comp_dofs = d_comp_dofs.p; a.classes = d_classes.p;
     a.gl_ptr = d_gl_ptr.p; a.gl_src = d_gl_src.p; a.dkind = d_dkind.p; a.dterm = d_dterm.p; a.dsrc = d_dsrc.p; a.dcls = d_dcls.p; a.dhdev = d_dhdev.p;
-    a.dpar = d_dpar.p; a.dmult = d_dmult.p; a.mosp = d_mosp.p; a.mos_cols = cols; a.kv = d_kv.p; a.srcv = d_srcv.p; a.dmask = d_dmask.p;
+    a.dpar = d_dpar.p; a.dmult = d_dmult.p; a.mosp = d_mosp.p; a.mos_cols = cols; a.kv = d_kv.p; a.srcv = d_kv.p + (size_t)Ssrc * A.known.size(); a.dmask = d_dmask.p;
     a.active = nullptr; a.gmin_s = d_gmin.p;
     a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = std::max(1, nsrc);
     a.n_unk = A.n_unk; a.n_mos_cls = n_cls;
@@ -346,8 +356,7 @@ struct ch_circuit {
     eval_sources(t, mode, sv, kv);
     std::memcpy(h_stage, kv.data(), kv.size() * sizeof(double));
     std::memcpy(h_stage + kv.size(), sv.data(), sv.size() * sizeof(double));
-    HIPCHK(hipMemcpyAsync(d_kv.p, h_stage, kv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_srcv.p, h_stage + kv.size(), sv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_kv.p, h_stage, (kv.size() + sv.size()) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     // the pinned staging buffer is reused next step: the stream sync at the end of the step protects it
     return CH_OK;
   }
@@ -359,8 +368,8 @@ struct ch_circuit {
     HIPCHK(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(newton_block_kernel, dim3(nblk), dim3(64), lds_bytes, st, a);
     HIPCHK(hipEventRecord(ev1, st));
-    hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 0, st, (const BlockOut*)d_out.p, A.n_comp, S, a.ck, a.ckm1, a.ckp1, active, d_sum.p);
-    HIPCHK(hipMemcpyAsync(h_sum, d_sum.p, sizeof(Summary), hipMemcpyDeviceToHost, st));
+    // the 64-byte summary is written straight into mapped pinned host memory (no D2H copy op)
+    hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 0, st, (const BlockOut*)d_out.p, A.n_comp, S, a.ck, a.ckm1, a.ckp1, active, h_sum);
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -435,7 +444,7 @@ struct ch_circuit {
         rc = run_newton(a, d_active.p, sm);
         if (rc != CH_OK) return rc;
       }
-      if (stt) { stt->nnonliniter += sm.sum_iters; stt->nf += sm.sum_iters; stt->njacs += sm.sum_iters; stt->nfactors += sm.sum_iters; stt->nsolve += sm.sum_iters; }
+      if (stt) { stt->n_block_iters += sm.sum_block_iters; stt->nnonliniter += sm.sum_iters; stt->nf += sm.sum_iters; stt->njacs += sm.sum_iters; stt->nfactors += sm.sum_iters; stt->nsolve += sm.sum_iters; }
       HIPCHK(hipMemcpy(bo.data(), d_out.p, nblk * sizeof(BlockOut), hipMemcpyDeviceToHost));
       n_active = 0;
       for (int b = 0; b < nblk; ++b) if (active[b]) { if (bo[b].status == 0) active[b] = 0; else ++n_active; }
@@ -541,10 +550,11 @@ struct ch_circuit {
       if (try_up) { extrap_weights(tau, kk + 2, a.wkp1); a.nkp1 = kk + 2; a.ckp1 = hh / (tn - tau[kk + 2]); }
       for (int j = 0; j < 7; ++j) a.hist_slot[j] = order[std::min(j, nh - 1)];
       a.cand_slot = order[NSLOT - 1];
-      rc = upload_sources(tn, 1); if (rc != CH_OK) { status = rc; break; }
+      // landing on a break point uses the sources' left limit there; the jump (if any) is crossed by the restart step
+      rc = upload_sources(hit_bp ? std::nextafter(tn, -INFINITY) : tn, 1); if (rc != CH_OK) { status = rc; break; }
       Summary sm;
       rc = run_newton(a, nullptr, sm); if (rc != CH_OK) { status = rc; break; }
-      R.stats.nnonliniter += sm.sum_iters; R.stats.nf += sm.sum_iters; R.stats.njacs += sm.sum_iters; R.stats.nfactors += sm.sum_iters; R.stats.nsolve += sm.sum_iters;
+      R.stats.n_block_iters += sm.sum_block_iters; R.stats.nnonliniter += sm.sum_iters; R.stats.nf += sm.sum_iters; R.stats.njacs += sm.sum_iters; R.stats.nfactors += sm.sum_iters; R.stats.nsolve += sm.sum_iters;
       if (sm.n_fail > 0) {
         R.stats.nnonlinconvfail++;
         h = hh * 0.25; k = 1; steps_at_order = 0;
@@ -554,8 +564,9 @@ struct ch_circuit {
       const double errk = lte ? sm.errk : 0.0;
       if (errk > 1.0) {
         R.stats.nreject++;
-        const double fac = std::max(0.1, 0.9 * std::pow(errk, -1.0 / (kk + 1)));
-        h = hh * std::min(fac, 0.9);
+        // IDA-style: aim at half the tolerance after a failed error test, shrink by at most 4x
+        const double fac = 0.9 * std::pow(2.0 * errk + 1e-4, -1.0 / (kk + 1));
+        h = hh * std::min(0.9, std::max(0.25, fac));
         steps_at_order = 0;
         continue;
       }
@@ -574,16 +585,17 @@ struct ch_circuit {
       } else { const double one = 1.0; rc = save(tn, order, &one, 1); }
       if (rc != CH_OK) { status = rc; break; }
       // ---- order / step selection ----
-      const double fac_k = 0.9 * std::pow(std::max(errk, 1e-10), -1.0 / (kk + 1));
+      const double fac_k = std::pow(2.0 * errk + 1e-4, -1.0 / (kk + 1));  // puts the error at half the tolerance
       double best = fac_k; int knew = kk;
       if (lte) {
         ++steps_at_order;
-        if (kk > 1) { const double f = 0.9 * std::pow(std::max(sm.errkm1, 1e-10), -1.0 / kk); if (f > best) { best = f; knew = kk - 1; } }
-        if (try_up) { const double f = 0.9 * std::pow(std::max(sm.errkp1, 1e-10), -1.0 / (kk + 2)); if (f > 1.1 * best) { best = f; knew = kk + 1; } }
+        if (kk > 1) { const double f = std::pow(2.0 * sm.errkm1 + 1e-4, -1.0 / kk); if (f > best) { best = f; knew = kk - 1; } }
+        if (try_up) { const double f = std::pow(2.0 * sm.errkp1 + 1e-4, -1.0 / (kk + 2)); if (f > 1.1 * best) { best = f; knew = kk + 1; } }
       } else knew = 1;
       if (knew != kk) steps_at_order = 0;
       k = knew;
-      h = std::min(dtmax, hh * std::min(kk == 1 ? 10.0 : 2.0, std::max(0.2, best)));
+      if (best > 1.0 && best < 1.2) best = 1.0;  // dead band: keep h when the suggested change is small
+      h = std::min(dtmax, hh * std::min(kk == 1 ? 10.0 : 2.0, std::max(0.5, best)));
       t = tn;
       if (hit_bp && t < t1) {
         nhist = 1; k = 1; steps_at_order = 0;

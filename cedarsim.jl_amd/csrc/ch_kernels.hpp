@@ -24,7 +24,7 @@
 namespace chip {
 
 struct ClassMeta {
-  int nc, ndev;
+  int nc, ndev, nonlinear, pad;
   int mat_ptr_ofs, mat_src_ofs, vec_ptr_ofs, vec_src_ofs;  // offsets into the pooled gather arrays
 };
 
@@ -40,6 +40,7 @@ struct BlockOut {
 struct Summary {
   int n_fail, max_iters, n_singular, pad;
   long long sum_iters;
+  long long sum_block_iters;
   double errk, errkm1, errkp1;  // max over samples of WRMS
   double fnorm;
 };
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(64) void newton_block_kernel(const NewtonArgs a) {
     ++iters;
     // (4) update
     double scale = 1.0;
-    if (a.mode == MODE_DC && a.dv_max > 0.0) {
+    if (a.mode == MODE_DC && a.dv_max > 0.0 && cm.nonlinear) {  // linear blocks take the full Newton step
       double m = 0.0;
       for (int i = lane; i < nc; i += 64) if (!(a.dmask[uofs + i] & 2)) m = fmax(m, fabs(A[i * lda + nc]));
       m = wave_max(m);
@@ -322,39 +323,62 @@ __global__ __launch_bounds__(64) void newton_block_kernel(const NewtonArgs a) {
 }
 
 // Reduce per-block outputs: WRMS per sample (over all blocks of the sample), max over samples.
+// Many samples: one thread per sample loops over the sample's blocks.  Few samples (a single large
+// circuit): the 256 threads split the blocks of one sample and tree-reduce in LDS.
+struct RedAcc {
+  double a, b, c, f; long long nd, bits; int nfail, nsing, mx;
+};
+__device__ __forceinline__ void red_add(RedAcc& x, const BlockOut& o) {
+  x.a += o.e2k; x.b += o.e2km1; x.c += o.e2kp1; x.nd += o.ndiff; x.bits += o.iters;
+  if (o.status != 0) ++x.nfail;
+  if (o.status == 2) ++x.nsing;
+  x.mx = max(x.mx, o.iters); x.f = fmax(x.f, o.fnorm);
+}
 __global__ __launch_bounds__(256) void reduce_blocks_kernel(const BlockOut* out, int n_comp, int S, double ck, double ckm1, double ckp1,
                                                             const unsigned char* active, Summary* sum) {
   __shared__ double sk[256], sm[256], sp[256], sf[256];
   __shared__ int sfail[256], smax[256], ssing[256];
-  __shared__ long long sit[256];
+  __shared__ long long sit[256], sbi[256], snd[256];
   const int t = threadIdx.x;
-  double mk_ = 0.0, mm = 0.0, mp = 0.0, mf = 0.0; int nfail = 0, mx = 0, nsing = 0; long long its = 0;
-  for (int s = t; s < S; s += 256) {
-    double a = 0.0, b = 0.0, c = 0.0; long nd = 0; int smx = 0;
-    for (int k = 0; k < n_comp; ++k) {
-      const int blk = k * S + s;
-      if (active && !active[blk]) continue;
-      const BlockOut o = out[blk];
-      a += o.e2k; b += o.e2km1; c += o.e2kp1; nd += o.ndiff;
-      if (o.status != 0) ++nfail;
-      if (o.status == 2) ++nsing;
-      smx = max(smx, o.iters);
-      mf = fmax(mf, o.fnorm);
+  double mk_ = 0.0, mm = 0.0, mp = 0.0, mf = 0.0; int nfail = 0, mx = 0, nsing = 0; long long its = 0, bits = 0;
+  if (S >= 64) {
+    for (int s = t; s < S; s += 256) {
+      RedAcc x{0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < n_comp; ++k) { const int blk = k * S + s; if (active && !active[blk]) continue; red_add(x, out[blk]); }
+      its += x.mx; mx = max(mx, x.mx); nfail += x.nfail; nsing += x.nsing; bits += x.bits; mf = fmax(mf, x.f);
+      if (x.nd > 0) { mk_ = fmax(mk_, ck * sqrt(x.a / x.nd)); mm = fmax(mm, ckm1 * sqrt(x.b / x.nd)); mp = fmax(mp, ckp1 * sqrt(x.c / x.nd)); }
     }
-    its += smx; mx = max(mx, smx);
-    if (nd > 0) { mk_ = fmax(mk_, ck * sqrt(a / nd)); mm = fmax(mm, ckm1 * sqrt(b / nd)); mp = fmax(mp, ckp1 * sqrt(c / nd)); }
+  } else {
+    for (int s = 0; s < S; ++s) {
+      RedAcc x{0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = t; k < n_comp; k += 256) { const int blk = k * S + s; if (active && !active[blk]) continue; red_add(x, out[blk]); }
+      sk[t] = x.a; sm[t] = x.b; sp[t] = x.c; sf[t] = x.f; snd[t] = x.nd; sbi[t] = x.bits; sfail[t] = x.nfail; ssing[t] = x.nsing; smax[t] = x.mx;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+          sk[t] += sk[t + o]; sm[t] += sm[t + o]; sp[t] += sp[t + o]; sf[t] = fmax(sf[t], sf[t + o]); snd[t] += snd[t + o]; sbi[t] += sbi[t + o];
+          sfail[t] += sfail[t + o]; ssing[t] += ssing[t + o]; smax[t] = max(smax[t], smax[t + o]);
+        }
+        __syncthreads();
+      }
+      if (t == 0) {
+        its += smax[0]; mx = max(mx, smax[0]); nfail += sfail[0]; nsing += ssing[0]; bits += sbi[0]; mf = fmax(mf, sf[0]);
+        if (snd[0] > 0) { mk_ = fmax(mk_, ck * sqrt(sk[0] / snd[0])); mm = fmax(mm, ckm1 * sqrt(sm[0] / snd[0])); mp = fmax(mp, ckp1 * sqrt(sp[0] / snd[0])); }
+      }
+      __syncthreads();
+    }
   }
-  sk[t] = mk_; sm[t] = mm; sp[t] = mp; sf[t] = mf; sfail[t] = nfail; smax[t] = mx; ssing[t] = nsing; sit[t] = its;
+  sk[t] = mk_; sm[t] = mm; sp[t] = mp; sf[t] = mf; sfail[t] = nfail; smax[t] = mx; ssing[t] = nsing; sit[t] = its; sbi[t] = bits;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (t < o) {
       sk[t] = fmax(sk[t], sk[t + o]); sm[t] = fmax(sm[t], sm[t + o]); sp[t] = fmax(sp[t], sp[t + o]); sf[t] = fmax(sf[t], sf[t + o]);
-      sfail[t] += sfail[t + o]; smax[t] = max(smax[t], smax[t + o]); ssing[t] += ssing[t + o]; sit[t] += sit[t + o];
+      sfail[t] += sfail[t + o]; smax[t] = max(smax[t], smax[t + o]); ssing[t] += ssing[t + o]; sit[t] += sit[t + o]; sbi[t] += sbi[t + o];
     }
     __syncthreads();
   }
   if (t == 0) {
-    Summary r; r.n_fail = sfail[0]; r.max_iters = smax[0]; r.n_singular = ssing[0]; r.pad = 0; r.sum_iters = sit[0];
+    Summary r; r.n_fail = sfail[0]; r.max_iters = smax[0]; r.n_singular = ssing[0]; r.pad = 0; r.sum_iters = sit[0]; r.sum_block_iters = sbi[0];
     r.errk = sk[0]; r.errkm1 = sm[0]; r.errkp1 = sp[0]; r.fnorm = sf[0];
     *sum = r;
   }

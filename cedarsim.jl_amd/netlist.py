@@ -298,7 +298,8 @@ class ParsedNetlist:
             name, toks = st[1], st[2]
             full = prefix + name
             pos, kw = _split_params(toks)
-            m = mult * (val(kw.pop("m")) if "m" in kw else 1.0)
+            m_given = "m" in kw
+            m = mult * (val(kw.pop("m")) if m_given else 1.0)
             c0 = name[0]
             if c0 == "r":
                 a, b = node(pos[0]), node(pos[1])
@@ -312,6 +313,9 @@ class ParsedNetlist:
                         base = rest[0].lower()
                         if base in self.models:
                             mp = self.models[base][0][2]
+                    if "r" in mp:  # `.model rm r R=1` (test/basic.jl:585-587)
+                        ckt.R(full, a, b, mp["r"], m=m)
+                        continue
                     ckt.R(full, a, b, None, m=m, rsh=mp.get("rsh", 50.0), w=val(kw["w"]) if "w" in kw else 1e-6,
                           l=val(kw["l"]) if "l" in kw else 1e-6, narrow=mp.get("narrow", 0.0), short=mp.get("short", 0.0))
                 else:
@@ -356,6 +360,8 @@ class ParsedNetlist:
                     if len(nodes) != len(sc.ports):
                         raise CedarError("subckt %s expects %d nodes, got %d" % (target, len(sc.ports), len(nodes)))
                     nm = {p: node(n) for p, n in zip(sc.ports, nodes)}
+                    if not m_given and "m" in sc.params:  # `.subckt r10 a b m=10`: default multiplicity (test/basic.jl:563)
+                        m = mult * eval_expr(sc.params["m"], env)
                     ip = {k: val(v) for k, v in kw.items()}
                     self._expand(ckt, sc, full + ".", nm, env, ip, m, ov)
                 elif target in self.models:

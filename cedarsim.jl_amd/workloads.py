@@ -1,0 +1,146 @@
+"""Benchmark / test workloads of BASELINE.json as flat `Circuit`s.
+
+The GF180 D-flip-flop topology below restates, as a Python table, the standard cell the reference
+simulates (test/DFF/gf180mcu_fd_sc_mcu7t5v0__dffnq_4.ngspice:4-58: 30 MOSFETs, 15 n + 15 p, 8
+distinct geometries) and its test bench (test/DFF/DFF_cap_all.cir:5-36: VDD = 5 V, CQ = 172.05 fF
+behind a 0 V ammeter source, well ties, CLKN and D piece-wise-linear stimuli with 1.02 ns edges,
+`.option gmin=1e-15`).  Device cards: substitute BSIM4 cards in data/gf180_substitute.lib (the real
+GF180MCUPDK cards are not available).
+"""
+import os
+
+import numpy as np
+
+from .circuit import PWL, Circuit
+from .netlist import parse_spice
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SUBSTITUTE_LIB = os.path.join(_HERE, "data", "gf180_substitute.lib")
+
+
+def gf180_resolver(path):
+    """lib_resolver for `.LIB "jlpkg://GF180MCUPDK/..."` (test/DFF/DFF_cap_all.cir:37)."""
+    if path.startswith("jlpkg://GF180MCUPDK"):
+        with open(SUBSTITUTE_LIB) as f:
+            return f.read()
+    return None
+
+
+_models_cache = {}
+
+
+def gf180_models():
+    """(name, type, params) of the two substitute cards."""
+    if not _models_cache:
+        nl = parse_spice("* cards\n.lib 'jlpkg://GF180MCUPDK/sm141064.ngspice' typical\n", lib_resolver=gf180_resolver)
+        for base, bins in nl.models.items():
+            _models_cache[base] = bins[0]
+    return _models_cache
+
+
+# (name, drain, gate, source, bulk, model, W, L) — ports of the cell: D CLKN Q VDD VNW VPW VSS
+WN, WP = 3.6e-07, 4.95e-07
+DFF_FETS = [
+    ("tn10", "VSS", "D", "D_neg", "VPW", "n", WN), ("tp10", "VDD", "D", "D_neg", "VNW", "p", WP),
+    ("tn11", "D_neg", "cki", "D_neg_clked", "VPW", "n", WN), ("tp11", "D_neg_clked", "ncki", "D_neg", "VNW", "p", WP),
+    ("tn15", "Q_internal", "D_neg_clked", "VSS", "VPW", "n", WN), ("tp15", "Q_internal", "D_neg_clked", "VDD", "VNW", "p", WP),
+    ("tn0", "D_neg_clked", "ncki", "net11", "VPW", "n", WN), ("tp0", "net4", "cki", "D_neg_clked", "VNW", "p", WP),
+    ("tn1", "VSS", "Q_internal", "net11", "VPW", "n", WN), ("tp1", "VDD", "Q_internal", "net4", "VNW", "p", WP),
+    ("tn2", "net0", "ncki", "Q_internal", "VPW", "n", WN), ("tp7", "net0", "cki", "Q_internal", "VNW", "p", WP),
+    ("tn3", "net7", "cki", "net0", "VPW", "n", WN), ("tp6", "net7", "ncki", "net0", "VNW", "p", WP),
+    ("tn5", "Q_neg", "net0", "VSS", "VPW", "n", 9.45e-07), ("tp3", "Q_neg", "net0", "VDD", "VNW", "p", 1.075e-06),
+    ("tn4", "VSS", "Q_neg", "net7", "VPW", "n", 9.45e-07), ("tp2", "VDD", "Q_neg", "net7", "VNW", "p", 1.075e-06),
+    ("tn6_7", "Q", "Q_neg", "VSS", "VPW", "n", 8.2e-07), ("tn6", "Q", "Q_neg", "VSS", "VPW", "n", 8.2e-07),
+    ("tn6_7_61", "Q", "Q_neg", "VSS", "VPW", "n", 8.2e-07), ("tn6_49", "Q", "Q_neg", "VSS", "VPW", "n", 8.2e-07),
+    ("tp4_13", "Q", "Q_neg", "VDD", "VNW", "p", 10.95e-07), ("tp4", "Q", "Q_neg", "VDD", "VNW", "p", 10.95e-07),
+    ("tp4_13_64", "Q", "Q_neg", "VDD", "VNW", "p", 10.95e-07), ("tp4_55", "Q", "Q_neg", "VDD", "VNW", "p", 10.95e-07),
+    ("tn9", "ncki", "CLKN", "VSS", "VPW", "n", 4.65e-07), ("tp9", "ncki", "CLKN", "VDD", "VNW", "p", 8.65e-07),
+    ("tn16", "cki", "ncki", "VSS", "VPW", "n", 4.65e-07), ("tp16", "cki", "ncki", "VDD", "VNW", "p", 8.65e-07),
+]
+DFF_SHARED = ("VDD", "VSS", "VNW", "VPW", "CLKN", "D")
+LN, LP = 6e-07, 5e-07
+
+CLKN_PWL = [0.0, 5.0, 50e-9, 5.0, 51.02e-9, 0.0, 100e-9, 0.0, 101.02e-9, 5.0, 400e-9, 5.0, 401.02e-9, 0.0,
+            500e-9, 0.0, 501.02e-9, 5.0, 600e-9, 5.0, 601.02e-9, 0.0, 700e-9, 0.0]
+D_PWL = [0.0, 0.0, 200e-9, 0.0, 201.02e-9, 5.0, 300e-9, 5.0, 301.02e-9, 0.0, 400e-9, 0.0, 401.02e-9, 5.0, 600e-9, 5.0]
+DFF_TSPAN = (0.0, 7e-7)            # test/gf180_dff.jl:24
+DFF_CHECK_TIMES = (1.5e-7, 2.5e-7, 4.5e-7, 5.5e-7, 7.0e-7)
+DFF_CHECK_Q = (0.0, 0.0, 5.0, 5.0, 5.0)  # test/gf180_dff.jl:29-33
+
+
+def dff_array(n_tiles=1, skew=None, observe="q", gmin=1e-15):
+    """SURVEY §8(d) config 2 (n_tiles=1) and config 3 (n_tiles=1024): tiled DFFs sharing the supplies,
+    wells, CLKN and D; each tile has its 12 private nodes, its own CQ and its own VQ ammeter.
+
+    skew: optional per-tile clock delay in seconds (array of n_tiles) — gives every tile a private
+    clock source (config 3 "optional per-tile clock skew U(0, 50 ps), seed 1234").
+    """
+    c = Circuit(gmin=gmin)
+    m = gf180_models()
+    mi = {"n": c.add_model(*m["nfet_06v0"]), "p": c.add_model(*m["pfet_06v0"])}
+    c.V("vvdd", "vdd", 0, dc=5.0)
+    c.V("vvss", "vss", 0, dc=0.0)
+    c.V("vnw", "vnw", "vdd", dc=0.0)
+    c.V("vpw", "vpw", "vss", dc=0.0)
+    if skew is None:
+        c.V("vclkn", "clkn", 0, tran=PWL(CLKN_PWL))
+    c.V("vd", "d", 0, tran=PWL(D_PWL))
+    for t in range(n_tiles):
+        pre = "" if n_tiles == 1 else "x%d." % t
+
+        def nn(name):
+            ln = name.lower()
+            if name in DFF_SHARED:
+                if name == "CLKN" and skew is not None:
+                    return pre + "clkn"
+                return ln
+            return pre + ln
+
+        if skew is not None:
+            w = list(CLKN_PWL)
+            for i in range(2, len(w), 2):
+                w[i] += float(skew[t])
+            c.V(pre + "vclkn", nn("CLKN"), 0, tran=PWL(w))
+        for name, d, g, s, b, typ, w in DFF_FETS:
+            c.M(pre + "x_" + name, nn(d), nn(g), nn(s), nn(b), mi[typ], w, LN if typ == "n" else LP)
+        c.C(pre + "cq", pre + "q_tmp", 0, 1.7205e-13)
+        c.V(pre + "vq", nn("Q"), pre + "q_tmp", dc=0.0)
+        if observe == "q" or (observe == "q0" and t == 0):
+            c.observe_node(nn("Q"))
+    return c
+
+
+INVERTER_NETLIST = """* Inverter test (test/inverter.jl:58-81)
+Xneg VSS D Q VSS nfet_06v0 W=3.6e-07 L=6e-07
+Xpos VDD D Q VDD pfet_06v0 W=4.95e-07 L=5e-07
+VVDD VDD 0 5.0
+VVSS VSS 0 0.0
+CQ D 0 1e-15
+VD D 0 PWL(
++ 000.0e-9 0.0
++ 100.0e-9 0.0
++ 110.0e-9 5.0
++ 200.0e-9 5.0
++ 210.0e-9 0.0
++ 300.0e-9 0.0
++ 310.0e-9 5.0
++ 400.0e-9 5.0
++ )
+.LIB "jlpkg://GF180MCUPDK/sm141064.ngspice" typical
+.END
+"""
+
+
+def inverter():
+    """SURVEY §8(d) config 1."""
+    c = parse_spice(INVERTER_NETLIST, lib_resolver=gf180_resolver).build()
+    c.observe_node("q")
+    c.observe_node("d")
+    return c
+
+
+def mc_samples(n_samples, seed=2024, sigma=0.03):
+    """Config 4 sample table: per-sample multipliers on vth0/u0/toxe of both cards, N(1, sigma),
+    generated host-side (the reference has no working sampler: src/simulate_ir.jl:18-19)."""
+    rng = np.random.default_rng(seed)
+    return {k: 1.0 + sigma * rng.standard_normal(n_samples) for k in ("n.vth0", "n.u0", "n.toxe", "p.vth0", "p.u0", "p.toxe")}

@@ -141,6 +141,7 @@ typedef struct ch_stats {
   double dc_seconds;       /* of which DC initialisation                        */
   double device_seconds;   /* sum of dominant-kernel durations measured with HIP events (0 for oracle) */
   int64_t n_kernel_launches;
+  int64_t n_block_iters;   /* Newton iterations summed over every Jacobian block (exact work count) */
 } ch_stats;
 
 /* CedarDCOp options (src/dcop.jl:24-28, 53-94) */

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import oracle_binding
+    oracle_binding.build()
+    return oracle_binding.lib()
+
+
+@pytest.fixture(scope="session")
+def gf180():
+    from cedarsim_jl_amd.workloads import gf180_resolver
+    return gf180_resolver

@@ -1,0 +1,357 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP engine, called through the C-ABI
+(libcedarhip.so via ctypes), against the CPU oracle on the same seeded inputs, against the
+reference's closed-form answers, and — at BASELINE.json's full size — through size-independent
+properties.  Tolerances: rtol 1e-6 on DC operating points, 1e-4 on transient waveforms
+(BASELINE.json north_star); device stamps 1e-10 (fp64, different libm)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cedarsim_jl_amd import (PULSE, SIN, Circuit, CircuitSweep, ProductSweep, dc, dc_opts, frange, parse_spice,
+                             parse_spice_file, tran, tran_opts)
+from cedarsim_jl_amd import bsim4_params as B4
+from cedarsim_jl_amd.workloads import (DFF_CHECK_Q, DFF_CHECK_TIMES, dff_array, gf180_resolver, inverter)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+G = json.load(open(os.path.join(GOLD, "closed_form.json")))
+DEFTOL = 1e-7
+
+
+@pytest.fixture(scope="module")
+def E():
+    from cedarsim_jl_amd.engine import EngineCircuit, load_library
+    load_library()  # fails loudly if the HIP extension is missing
+    return EngineCircuit
+
+
+@pytest.fixture(scope="module")
+def O(oracle_lib):
+    from oracle_binding import Oracle
+    return Oracle
+
+
+def approx(a, b, tol=DEFTOL):
+    return abs(a - b) <= max(tol, tol * max(abs(a), abs(b)))
+
+
+def canon(c, x, nu):
+    """Make an MNA vector consistent with the engine's aliases: merged nodes share one voltage."""
+    x = x.copy()
+    first = {}
+    for n in range(1, c.n_nodes + 1):
+        if nu[n] >= 0:
+            if nu[n] in first:
+                x[n - 1] = x[first[nu[n]] - 1]
+            else:
+                first[nu[n]] = n
+    return x
+
+
+def reduce_rows(c, nu, F, J=None):
+    """Sum oracle rows/columns of merged nodes; keep only rows of the engine's unknowns."""
+    groups = {}
+    for n in range(1, c.n_nodes + 1):
+        if nu[n] >= 0:
+            groups.setdefault(int(nu[n]), []).append(n - 1)
+    reps = [g[0] for g in groups.values()]
+    Fr = np.array([sum(F[i] for i in g) for g in groups.values()])
+    Jr = None if J is None else np.array([[sum(J[i, j] for i in g for j in h) for h in groups.values()] for g in groups.values()])
+    return reps, Fr, Jr
+
+
+# ------------------------------------------------------------------------------------------------
+# device level
+def test_bsim4_stamps_match_oracle(E, O):
+    c = dff_array(1)
+    e, o = E(c), O(c)
+    rng = np.random.default_rng(0)
+    for scale, lo in ((6.5, -0.75), (0.2, 2.4), (12.0, -3.0)):
+        v = lo + scale * rng.random((30, 4))
+        a, b = e.mos_eval(v), o.mos_eval(v)
+        sc = np.maximum(np.abs(b).max(axis=0, keepdims=True), 1e-30)
+        assert np.max(np.abs(a - b) / sc) < 1e-10
+    # edge cases: vds = 0 exactly, reverse mode, forward-biased junctions, deep subthreshold
+    v = np.array([[2.0, 3.0, 2.0, 0.0], [0.5, 3.0, 4.0, 0.0], [0.0, 5.0, 0.0, 0.9], [5.0, -2.0, 0.0, 0.0]] + [[1, 1, 1, 1.0]] * 26)
+    a, b = e.mos_eval(v), o.mos_eval(v)
+    sc = np.maximum(np.abs(b).max(axis=0, keepdims=True), 1e-30)
+    assert np.max(np.abs(a - b) / sc) < 1e-10
+
+
+def test_residual_jacobian_assembly_matches_oracle(E, O):
+    """prob.f.f / prob.f.jac equivalents (benchmarks/benchmark_common.jl:138,155) on the DFF."""
+    c = dff_array(1)
+    e, o = E(c), O(c)
+    nu, nk, bu = e.maps()
+    info = e.info()
+    assert info["n_unknowns"] == 11 and info["n_known"] == 6 and info["n_alias"] == 1 and info["n_components"] == 1
+    rc, xo, _ = o.dc(dc_opts(abstol=1e-14))
+    rng = np.random.default_rng(3)
+    x = xo + 0.05 * rng.standard_normal(xo.shape)
+    for n in range(1, c.n_nodes + 1):
+        if nu[n] < 0:
+            x[n - 1] = xo[n - 1]  # eliminated nodes hold their source-defined values
+    x = canon(c, x, nu)
+    for alpha0 in (0.0, 3e9):
+        Fe, Qe, Je = e.eval(x, t=0.0, alpha0=alpha0, mode=1)
+        Fo, Qo, Jo = o.eval(x, t=0.0, alpha0=alpha0, mode=1)
+        reps, Fo_r, Jo_r = reduce_rows(c, nu, Fo, Jo)
+        _, Qo_r, _ = reduce_rows(c, nu, Qo)
+        assert np.max(np.abs(Fe[reps] - Fo_r)) <= 1e-10 * np.max(np.abs(Fo_r))
+        assert np.max(np.abs(Qe[reps] - Qo_r)) <= 1e-10 * np.max(np.abs(Qo_r))
+        assert np.max(np.abs(Je[np.ix_(reps, reps)] - Jo_r)) <= 1e-10 * np.max(np.abs(Jo_r))
+
+
+# ------------------------------------------------------------------------------------------------
+# DC: closed forms of the reference's tests, through the host mirror API
+def test_dc_closed_forms():
+    c = Circuit()
+    c.V("V", "vcc", 0, dc=5.0)
+    c.R("R", "vcc", 0, 2.0)
+    sol = dc(c)
+    assert sol.retcode == "Success" and approx(sol["R.V"][0], 5.0) and approx(sol["R.I"][0], 2.5) and approx(sol["V.I"][0], -2.5)
+    c = Circuit()
+    c.I("I", "icc", 0, dc=-5.0)
+    c.R("R", "icc", 0, 2.0)
+    sol = dc(c)
+    assert approx(sol["icc"][0], 10.0) and approx(sol["R.I"][0], 5.0)
+
+
+MULT = """* multiplicities
+v1 vcc 0 DC 1
+r1a vcc 1 1 m=10
+r1b 1 0 1
+.subckt r10 a b m=10
+r2a a b 1
+.ends
+x2a vcc 2 r10
+r2b 2 0 1
+x3a1 vcc 3 r10 m=5
+x3a2 vcc 3 r10 m=5
+r3b 3 0 1
+.subckt r5t2 a b
+x5r1 a b r10 m=5
+x5r2 a b r10 m=5
+.ends
+x4a1 vcc 4 r5t2
+r4b 4 0 1
+.subckt r2 a b
+r2 a b 1 m=2
+.ends
+x5a vcc 5 r2 m=5
+r5b 5 0 1
+.model rm r R=1
+r6a vcc 6 rm m=10 l=1u
+r6b 6 0 1
+"""
+
+
+def test_dc_multiplicities_and_sources():
+    sol = dc(parse_spice(MULT).build(), abstol=1e-14)  # test/basic.jl:556-595
+    for n in "123456":
+        assert abs(sol[n][0] - 10.0 / 11.0) < 1e-12
+    c = parse_spice("* sources\nv1 1 0 2\ne1 2 0 1 0 2\nr2 2 0 1\ng1 3 0 1 0 2\nr3 3 0 1k\nb1 4 0 v=4\nr4 4 0 1\n").build()
+    sol = dc(c)
+    assert approx(sol["2"][0], 4.0) and approx(sol["3"][0], -4000.0) and approx(sol["4"][0], 4.0)
+
+
+def test_dc_sweep_400_points_batched():
+    """test/sweep.jl:326-340: one batched GPU solve for the 20x20 sweep, I = -1/(R1+R2)."""
+    def two_resistor(R1=100.0, R2=100.0):
+        c = Circuit()
+        c.V("V", "vcc", 0, dc=1.0)
+        c.R("R1", "vcc", "mid", R1)
+        c.R("R2", "mid", 0, R2)
+        return c
+    cs = CircuitSweep(two_resistor, ProductSweep(R1=frange(100.0, 100.0, 2000.0), R2=frange(100.0, 100.0, 2000.0)))
+    sols = dc(cs, abstol=DEFTOL)
+    assert len(sols) == 400
+    for sol, p in zip(sols, cs):
+        assert sol.retcode == "Success"
+        assert approx(sol["V.I"][0], -1.0 / (p["R1"] + p["R2"]))
+
+
+def test_dc_sweep_on_spice_code():
+    """test/sweep.jl:342-371: sweep of a top-level and a subcircuit parameter, I = v_in/r_load."""
+    nl = parse_spice("""* Parameter scoping test
+.subckt subcircuit1 vss gnd
+.param r_load=1
+r1 vss gnd 'r_load'
+.ends
+.param v_in=1
+x1 vss 0 subcircuit1
+v1 vss 0 'v_in'
+""")
+    cs = CircuitSweep(nl, ProductSweep(**{"v_in": frange(1.0, 1.0, 10.0), "x1.r_load": frange(1.0, 1.0, 10.0)}))
+    sols = dc(cs, abstol=DEFTOL)
+    assert len(sols) == 100
+    for sol, p in zip(sols, cs):
+        assert approx(sol["x1.r1.I"][-1], p["v_in"] / p["x1.r_load"])
+
+
+def test_dc_operating_point_matches_oracle_rtol_1e6(E, O):
+    for c in (inverter(), dff_array(1)):
+        e, o = E(c), O(c)
+        rc, xo, _ = o.dc(dc_opts(abstol=1e-14))
+        assert rc == 0
+        rc, x, status, st = e.dc(dc_opts(abstol=1e-14, x0=xo[None, :]))  # same basin of the bistable DFF
+        assert rc == 0 and status[0] == 0
+        ok = ~np.isnan(x[0])
+        assert np.allclose(x[0][ok], xo[ok], rtol=1e-6, atol=1e-9)
+        # from a cold random start the engine converges too, to a point where the ORACLE's KCL holds
+        rc, x2, status, st = e.dc(dc_opts(abstol=1e-14))
+        assert rc == 0 and st["nnonliniter"] > 0
+        nu = e.maps()[0]
+        xs = canon(c, np.nan_to_num(x2[0]), nu)
+        Fo, _, _ = o.eval(xs, t=0.0, alpha0=0.0, mode=0)
+        _, Fr, _ = reduce_rows(c, nu, Fo)
+        assert np.max(np.abs(Fr)) < 1e-10
+
+
+def test_singular_and_invalid_inputs(E):
+    from cedarsim_jl_amd.circuit import CedarError
+    c = Circuit()
+    c.I("I", "a", 0, dc=1.0)
+    c.C("C", "a", 0, 1e-9)
+    rc, x, status, st = E(c).dc(dc_opts(n_restarts=2, maxiters=5))
+    assert rc != 0 and status[0] != 0
+    c = Circuit()
+    c.V("V1", "a", 0, dc=1.0)
+    c.V("V2", "a", 0, dc=2.0)  # loop of voltage sources
+    with pytest.raises(CedarError):
+        E(c)
+    with pytest.raises(CedarError):
+        Circuit().R("R", "a", 0, 1.0, m=-1.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# transient
+def test_transient_rc_and_pwl_closed_forms():
+    g = G["vrc"]
+    c = Circuit()
+    c.V("V", "vcc", 0, dc=g["V"])
+    c.R("R", "vcc", "vrc", g["R"])
+    c.C("C", "vrc", 0, g["C"])
+    u0 = np.zeros(c.n_mna)
+    u0[c.mna_index("v", "vcc")] = g["V"]
+    sol = tran(c, (0.0, 1.0), abstol=1e-9, reltol=1e-9, u0=u0)
+    assert sol.retcode == "Success"
+    cv = sol["C.V"]
+    assert approx(cv[0], 0.0) and approx(cv[-1], g["C.V(end)"])
+    assert approx((sol["vcc"][0] - sol["vrc"][0]) / g["R"], g["C.I(0)"])
+    tt = np.array([1e-3, 2e-3, 5e-3, 1e-2])
+    sol = tran(c, (0.0, 1.0), abstol=1e-9, reltol=1e-9, u0=u0, saveat=tt)
+    assert np.max(np.abs(sol["vrc"] - g["V"] * (1 - np.exp(-tt / (g["R"] * g["C"]))))) < 1e-6
+    # PWL current into a resistor (test/transients.jl:17-63) from SPICE text
+    p = G["pwl_ir"]
+    c = parse_spice("* PWL test\n.param pval=-1\ni1 vout 0 PWL(1m 0 9m 'pval*%g')\nR1 vout 0 r=%g\n" % (p["i_max"], p["r"])).build()
+    sol = tran(c, (0.0, 10e-3), abstol=1e-8, reltol=1e-8)
+    want = np.clip((sol.t - p["t0"]) / (p["t1"] - p["t0"]), 0, 1) * p["i_max"] * p["r"]
+    assert np.max(np.abs(sol["vout"] - want)) < DEFTOL
+
+
+def test_butterworth_closed_form():
+    g = G["butterworth"]
+    c = Circuit()
+    c.V("V1", "vin", 0, tran=SIN(0, 1, 1 / (2 * math.pi)))
+    c.L("L1", "vin", "n1", g["L1"])
+    c.C("C2", "n1", 0, g["C2"])
+    c.L("L3", "n1", "vout", g["L3"])
+    c.R("R4", "vout", 0, g["R4"])
+    sol = tran(c, (0.0, 100.0), abstol=1e-9, reltol=1e-9, u0=np.zeros(c.n_mna))
+    t = sol.t
+    an = (np.exp(-t) - np.sin(t) - np.cos(t)) / 2 + 2 * np.sin(np.sqrt(3) * t / 2) / (np.sqrt(3) * np.sqrt(np.exp(t)))
+    assert sol.retcode == "Success" and np.max(np.abs(sol["vout"] - an)) < DEFTOL
+
+
+def test_inverter_logic_levels_pwl_and_pulse():
+    """test/inverter.jl:40-50 (config 1), with PWL and with PULSE stimulus."""
+    g = G["inverter_gate"]
+    for variant in ("pwl", "pulse"):
+        c = inverter()
+        if variant == "pulse":
+            i = c.dev_names.index("vd")
+            c.sources[c.dev_ipar[i][0]] = (0.0, PULSE(0.0, 5.0, 100e-9, 10e-9, 10e-9, 100e-9, 200e-9))
+        sol = tran(c, (0.0, 4e-7), abstol=1e-8, reltol=1e-8, dc_abstol=1e-14, saveat=np.array(g["t"]))
+        assert sol.retcode == "Success"
+        for k in range(4):
+            assert approx(sol["d"][k], g["d"][k]) and approx(sol["q"][k], g["q"][k], g["tol"])
+
+
+def test_dff_waveform_matches_oracle_rtol_1e4(E, O):
+    """Config 2: one GF180 DFF, same initial state, waveform parity at rtol 1e-4 of the 5 V swing."""
+    c = dff_array(1)
+    for nm in ("q_neg", "net0", "d_neg_clked", "cki"):
+        c.observe_node(nm)
+    e, o = E(c), O(c)
+    rc, xo, _ = o.dc(dc_opts(abstol=1e-14))
+    sv = np.linspace(0.0, 7e-7, 1401)
+    tol = 1e-7
+    rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo[None, :])))
+    assert rc == 0
+    rco, to, vo, xfo, sto = o.tran(0.0, 7e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo)))
+    assert rco == 0 and len(t) == len(to) == len(sv)
+    err = np.max(np.abs(v[:, :, 0] - vo))
+    assert err < 1e-4 * 5.0, err
+    for tt, q in zip(DFF_CHECK_TIMES, DFF_CHECK_Q):  # test/gf180_dff.jl:29-33
+        assert abs(np.interp(tt, t, v[0, :, 0]) - q) < 1e-4
+
+
+def test_dff_reference_gate_from_cold_start():
+    """test/gf180_dff.jl: DC from random start (CedarDCOp abstol 1e-14), abstol 1e-5, netlist as shipped."""
+    nl = parse_spice_file(os.path.join(GOLD, "DFF_cap_all.cir"), lib_resolver=gf180_resolver)
+    sol = tran(nl, (0.0, 7e-7), abstol=1e-5, reltol=1e-3, dc_abstol=1e-14, observe=["q"])
+    assert sol.retcode == "Success"
+    for tt, q in zip(DFF_CHECK_TIMES, DFF_CHECK_Q):
+        assert abs(sol(tt, idxs="node_q") - q) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# batched samples (config 4 shape) and the full-size array (config 3)
+def test_monte_carlo_batch_matches_per_sample_oracle(E, O):
+    c = dff_array(1)
+    slots, names = [], []
+    for m in ("nfet_06v0", "pfet_06v0"):
+        for p in ("vth0", "u0", "toxe"):
+            slots.append(c.slot(m, p))
+            names.append((m, p))
+    S = 64
+    rng = np.random.default_rng(2024)
+    base = np.array([c.models[c.model_names.index(m)][B4.PARAM_INDEX[p]] for m, p in names])
+    vals = base[:, None] * (1.0 + 0.03 * rng.standard_normal((len(slots), S)))
+    e = E(c)
+    e.set_samples(S)
+    e.set_params(slots, vals)
+    assert e.info()["n_samples"] == S
+    sv = np.array([0.5e-7, 0.8e-7, 1.2e-7])
+    o = O(c)
+    rc, xo, _ = o.dc(dc_opts(abstol=1e-14))
+    x0 = np.tile(xo, (S, 1))
+    rc, t, v, xf, st = e.tran(0.0, 1.2e-7, tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, skip_dc=True, dc=dc_opts(x0=x0)))
+    assert rc == 0 and v.shape == (1, 3, S)
+    assert np.std(v[0, 1, :]) > 0  # samples really differ
+    for s in (0, 17, 63):
+        for k, sl in enumerate(slots):
+            o.set_param(sl, vals[k, s])
+        rco, to, vo, _, _ = o.tran(0.0, 1.2e-7, tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo)))
+        assert rco == 0 and np.max(np.abs(v[0, :, s] - vo[0])) < 1e-4 * 5.0
+
+
+def test_full_size_array_properties(E):
+    """Config 3 at BASELINE size: 1024 tiles / 30720 MOSFETs.  Size-independent properties:
+    (1) the reference's logic gate holds for every tile, (2) identical tiles produce identical
+    waveforms (tile equivalence: the blocks are decoupled)."""
+    c = dff_array(1024, observe="q")
+    e = E(c)
+    info = e.info()
+    assert info["n_mos"] == 30720 and info["n_components"] == 1024 and info["n_classes"] == 1 and info["n_unknowns"] == 1024 * 11
+    sv = np.array(DFF_CHECK_TIMES)
+    rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(abstol=1e-5, reltol=1e-5, saveat=sv, dc=dc_opts(abstol=1e-14)))
+    assert rc == 0 and v.shape == (1024, 5, 1)
+    q = v[:, :, 0]
+    assert np.max(np.abs(q - np.array(DFF_CHECK_Q)[None, :])) < 1e-4
+    assert np.max(np.abs(q - q[0:1])) < 1e-9  # tile equivalence
+    assert st["n_block_iters"] >= 1024 * st["naccept"]

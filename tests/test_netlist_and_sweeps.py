@@ -1,0 +1,116 @@
+"""Host logic: SPICE front-end semantics and the sweep iterators (mirrors test/sweep.jl:71-242,
+test/basic.jl:609-684,739-752, test/binning/bins.jl).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from cedarsim_jl_amd import (NoBinException, ProductSweep, SerialSweep, Sweep, TandemSweep, find_param_ranges, frange,
+                             parse_number, parse_spice, parse_spice_file, shard_range, sweepify, sweepvars)
+from cedarsim_jl_amd.circuit import CedarError
+from cedarsim_jl_amd.workloads import dff_array, gf180_resolver
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_magnitudes():  # src/spectre.jl:402-415, test/basic.jl:609-638
+    assert parse_number("1Meg") == 1e6 and parse_number("1meg") == 1e6
+    assert parse_number("1Mil") == 25.4e-6
+    assert parse_number("0.22u") == 0.22e-6  # exact, not 2.2000000000000001e-7
+    assert parse_number("10ns") == 1e-8 and parse_number("3.3333333333333e-10") == 3.3333333333333e-10
+    assert parse_number("1k") == 1e3 and parse_number("2.5m") == 2.5e-3 and parse_number("1f") == 1e-15
+    assert parse_number("5v") == 5.0 and parse_number("abc") is None
+
+
+def test_spice_functions_and_if_else():  # test/basic.jl:651-684, :739-752
+    nl = parse_spice("""* fn
+.param a='int(3.7)' b='nint(2.5)' c='floor(-1.5)' d='ceil(1.2)' e='pow(2,3)' f='ln(exp(2))'
+.param sel=1
+.if (sel==1)
+r1 1 0 'a+b+c+d+e+f'
+.else
+r1 1 0 1
+.endif
+v1 1 0 1
+""")
+    c = nl.build()
+    assert abs(c.dev_par[c.dev_names.index("r1")][0] - (3 + 3 - 2 + 2 + 8 + 2)) < 1e-12
+    assert abs(nl.build(sel=0).dev_par[0][0] - 1.0) < 1e-12
+
+
+def test_param_scoping_and_overrides():  # test/sweep.jl:342-371, test/params.jl:90-100
+    nl = parse_spice("""* Parameter scoping test
+.subckt subcircuit1 vss gnd
+.param r_load=1
+r1 vss gnd 'r_load'
+.ends
+.param v_in=1
+x1 vss 0 subcircuit1
+v1 vss 0 'v_in'
+""")
+    c = nl.build(**{"v_in": 3.0, "x1.r_load": 7.0})
+    assert c.dev_par[c.dev_names.index("x1.r1")][0] == 7.0 and c.sources[0][0] == 3.0
+    with pytest.raises(CedarError):
+        nl.build(nonexistent=1.0)
+
+
+def test_binning_find_bin():  # test/binning/bins.jl:19-20
+    nl = parse_spice_file(os.path.join(GOLD, "bins_nmos_3p3.cir"))
+    assert len(nl.models["nmos_3p3"]) == 16
+    assert nl.find_bin("nmos_3p3", 2.8e-7, 2.2e-7)[0] == "nmos_3p3.0"
+    assert nl.find_bin("nmos_3p3", 5.0e-7, 2.2e-7)[0] == "nmos_3p3.1"  # half-open ranges
+    with pytest.raises(NoBinException):
+        nl.find_bin("nmos_3p3", 1e-3, 1e-3)
+    # (the file's first line is the SPICE title line, so its m0 device is not part of the circuit)
+    text = "* binning\nm0 d1 g s1 b nmos_3p3 W=1e-6 l=1e-6\n" + open(os.path.join(GOLD, "bins_nmos_3p3.cir")).read().split("\n", 1)[1]
+    c = parse_spice(text).build()
+    assert c.model_names == ["nmos_3p3.5"]
+    assert c.models[0][__import__("cedarsim_jl_amd").bsim4_params.PARAM_INDEX["level"]] == 54.0
+
+
+def test_dff_netlist_matches_generated_workload(gf180):
+    nl = parse_spice_file(os.path.join(GOLD, "DFF_cap_all.cir"), lib_resolver=gf180)
+    a, b = nl.build(), dff_array(1)
+    assert a.gmin == b.gmin == 1e-15 and nl.tran == (3.3333333333333e-10, 6.0e-7)
+    assert a.n_nodes == b.n_nodes == 18 and a.n_mna == b.n_mna == 25
+    key = lambda c: sorted((c.dev_kind[i], tuple(c.node_names[n] for n in c.dev_node[i]), tuple(np.nan_to_num(c.dev_par[i], nan=-1)))
+                           for i in range(len(c.dev_kind)))
+    assert key(a) == key(b)
+    assert sorted(w.ts for _, w in a.sources if w.ts) == sorted(w.ts for _, w in b.sources if w.ts)
+
+
+def test_unknown_model_parameter_is_rejected():
+    with pytest.raises(CedarError):
+        parse_spice("* t\n.model n1 nmos level=54 notaparam=1\nm1 d g 0 0 n1 w=1u l=1u\n").build()
+
+
+# ---- sweeps (test/sweep.jl:71-242) ----
+def test_sweep_algebra():
+    s = Sweep("R1", frange(0.1, 0.1, 1.0))
+    assert len(s) == 10 and list(s)[0] == (("R1", 0.1),)
+    with pytest.raises(ValueError):
+        Sweep(R1=[1], R2=[2])
+    p = ProductSweep(R1=[1, 2, 3, 4], R2=[10, 20], R3=[5])
+    assert p.shape == (4, 2, 1) and len(p) == 8
+    pts = list(p)
+    assert pts[0] == (("R1", 1), ("R2", 10), ("R3", 5)) and pts[1][0] == ("R1", 2)  # first axis fastest
+    t = TandemSweep(R1=[1, 2, 3], R2=[4, 5, 6])
+    assert list(t)[2] == (("R1", 3), ("R2", 6))
+    with pytest.raises(ValueError):
+        TandemSweep(R1=[1, 2], R2=[1])
+    ss = SerialSweep(R1=[1, 2], R2=[3])
+    assert len(ss) == 3 and dict(list(ss)[0]) == {"R1": 1, "R2": None} and dict(list(ss)[2]) == {"R1": None, "R2": 3}
+    assert ProductSweep(R1=[1, 2]) == Sweep("R1", [1, 2])
+    assert sweepvars(p, ss) == {"R1", "R2", "R3"}
+    sw = sweepify([{"r1": [1, 2], "r2": [1, 2]}, {"r3": [1, 2, 3]}])
+    assert len(sw) == 7
+    assert find_param_ranges(p) == {"R1": (1, 4, 4), "R2": (10, 20, 2), "R3": (5, 5, 1)}
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 8192, 400):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
