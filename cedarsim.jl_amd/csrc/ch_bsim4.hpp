@@ -294,60 +294,83 @@ inline int b4_pack(const double* mp, const double* ip, double temp_c, double* ou
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------------------------------------
 // Device side.
-struct D3 {  // value + d/dVgs' + d/dVds' + d/dVbs'
-  double v, g, d, b;
+//
+// fp64 division and square root dominate the instruction count of a compact model; the IEEE
+// sequences hipcc emits cost ~11 / ~15 VALU instructions.  frcp/fsqrt use the hardware seeds
+// (v_rcp_f64, v_rsq_f64) plus Newton steps: <= 1-2 ulp, which is far inside the 1e-10 parity bar.
+CH_D double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+CH_D double fsqrt(double x) {  // x > 0
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return g;
+}
+
+// value + N partial derivatives.  N = 3: (d/dVgs', d/dVds', d/dVbs') in one lane.
+// N = 1: one partial per lane, four lanes per instance (the fourth carries a zero seed).
+template <int N>
+struct DN {
+  double v, p[N];
 };
-CH_D D3 mk(double v) { return D3{v, 0.0, 0.0, 0.0}; }
-CH_D D3 operator+(D3 a, D3 b) { return D3{a.v + b.v, a.g + b.g, a.d + b.d, a.b + b.b}; }
-CH_D D3 operator-(D3 a, D3 b) { return D3{a.v - b.v, a.g - b.g, a.d - b.d, a.b - b.b}; }
-CH_D D3 operator-(D3 a) { return D3{-a.v, -a.g, -a.d, -a.b}; }
-CH_D D3 operator+(D3 a, double b) { return D3{a.v + b, a.g, a.d, a.b}; }
-CH_D D3 operator+(double b, D3 a) { return D3{a.v + b, a.g, a.d, a.b}; }
-CH_D D3 operator-(D3 a, double b) { return D3{a.v - b, a.g, a.d, a.b}; }
-CH_D D3 operator-(double b, D3 a) { return D3{b - a.v, -a.g, -a.d, -a.b}; }
-CH_D D3 operator*(D3 a, double b) { return D3{a.v * b, a.g * b, a.d * b, a.b * b}; }
-CH_D D3 operator*(double b, D3 a) { return D3{a.v * b, a.g * b, a.d * b, a.b * b}; }
-CH_D D3 operator*(D3 a, D3 b) {
-  return D3{a.v * b.v, fma(a.g, b.v, a.v * b.g), fma(a.d, b.v, a.v * b.d), fma(a.b, b.v, a.v * b.b)};
+template <int N> CH_D DN<N> mkd(double v) { DN<N> r; r.v = v; for (int i = 0; i < N; ++i) r.p[i] = 0.0; return r; }
+template <int N> CH_D DN<N> operator+(DN<N> a, DN<N> b) { DN<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.p[i] = a.p[i] + b.p[i]; return r; }
+template <int N> CH_D DN<N> operator-(DN<N> a, DN<N> b) { DN<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.p[i] = a.p[i] - b.p[i]; return r; }
+template <int N> CH_D DN<N> operator-(DN<N> a) { DN<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.p[i] = -a.p[i]; return r; }
+template <int N> CH_D DN<N> operator+(DN<N> a, double b) { a.v += b; return a; }
+template <int N> CH_D DN<N> operator+(double b, DN<N> a) { a.v += b; return a; }
+template <int N> CH_D DN<N> operator-(DN<N> a, double b) { a.v -= b; return a; }
+template <int N> CH_D DN<N> operator-(double b, DN<N> a) { DN<N> r; r.v = b - a.v; for (int i = 0; i < N; ++i) r.p[i] = -a.p[i]; return r; }
+template <int N> CH_D DN<N> operator*(DN<N> a, double b) { DN<N> r; r.v = a.v * b; for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * b; return r; }
+template <int N> CH_D DN<N> operator*(double b, DN<N> a) { return a * b; }
+template <int N> CH_D DN<N> operator*(DN<N> a, DN<N> b) { DN<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.p[i] = fma(a.p[i], b.v, a.v * b.p[i]); return r; }
+template <int N> CH_D DN<N> recip(DN<N> a) { const double r = frcp(a.v), m = -r * r; DN<N> o; o.v = r; for (int i = 0; i < N; ++i) o.p[i] = a.p[i] * m; return o; }
+template <int N> CH_D DN<N> operator/(DN<N> a, DN<N> b) {
+  const double r = frcp(b.v), q = a.v * r;
+  DN<N> o; o.v = q; for (int i = 0; i < N; ++i) o.p[i] = fma(-q, b.p[i], a.p[i]) * r; return o;
 }
-CH_D D3 recip(D3 a) { const double r = 1.0 / a.v, m = -r * r; return D3{r, a.g * m, a.d * m, a.b * m}; }
-CH_D D3 operator/(D3 a, D3 b) {
-  const double r = 1.0 / b.v, q = a.v * r;
-  return D3{q, (a.g - q * b.g) * r, (a.d - q * b.d) * r, (a.b - q * b.b) * r};
-}
-CH_D D3 operator/(D3 a, double b) { return a * (1.0 / b); }
-CH_D D3 operator/(double a, D3 b) { return recip(b) * a; }
-// apply a scalar function given its value f and derivative fp at a.v
-CH_D D3 chain(D3 a, double f, double fp) { return D3{f, a.g * fp, a.d * fp, a.b * fp}; }
-CH_D D3 dsqrt(D3 a) { const double s = sqrt(a.v); return chain(a, s, 0.5 / s); }
-CH_D D3 dexp(D3 a) { const double e = exp(a.v); return chain(a, e, e); }
-CH_D D3 dlog(D3 a) { return chain(a, log(a.v), 1.0 / a.v); }
+template <int N> CH_D DN<N> operator/(DN<N> a, double b) { return a * frcp(b); }
+template <int N> CH_D DN<N> operator/(double a, DN<N> b) { return recip(b) * a; }
+template <int N> CH_D DN<N> chain(DN<N> a, double f, double fp) { DN<N> r; r.v = f; for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * fp; return r; }
+template <int N> CH_D DN<N> dsqrt(DN<N> a) { const double s = fsqrt(a.v); return chain(a, s, 0.5 * frcp(s)); }
+template <int N> CH_D DN<N> dexp(DN<N> a) { const double e = exp(a.v); return chain(a, e, e); }
+template <int N> CH_D DN<N> dlog(DN<N> a) { return chain(a, log(a.v), frcp(a.v)); }
 
 // smooth SCE factor e^x/((e^x-1)^2 + 2 e^x MIN_EXP)
-CH_D D3 d_sce(D3 x) {
+template <int N> CH_D DN<N> d_sce(DN<N> x) {
   if (x.v < k::EXP_TH) {
-    const D3 e = dexp(x), m1 = e - 1.0;
+    const DN<N> e = dexp(x), m1 = e - 1.0;
     return e / (m1 * m1 + e * (2.0 * k::MIN_EXP));
   }
-  return mk(1.0 / (k::MAX_EXP - 2.0));
+  return mkd<N>(1.0 / (k::MAX_EXP - 2.0));
 }
 
 struct B4Col {
-  const double* p;  // base of the packed table
-  long stride;      // distance between consecutive parameters (= number of columns)
-  long col;
-  CH_D double operator[](int i) const { return p[(long)i * stride + col]; }
+  // One packed column per class, parameters contiguous ([column][B4I_COUNT]): the ~140 values one
+  // lane needs sit in 9 consecutive cache lines, and the 8 classes of a DFF block fit in L1.
+  const double* p;  // base of this lane's column
+  CH_D double operator[](int i) const { return p[i]; }
 };
+CH_D B4Col b4_col(const double* table, long col) { return B4Col{table + col * (long)B4I_COUNT}; }
 
 // junction diode current and conductance (dioMod 1) incl. gmin
 CH_D void diode(double vb, double Is, double Nvtm, double vjm, double IVjm, double gmin, double& i, double& g) {
   if (Is <= 0.0) { i = gmin * vb; g = gmin; return; }
+  const double iN = frcp(Nvtm);
   if (vb <= vjm) {
-    const double t = vb / Nvtm;
+    const double t = vb * iN;
     if (t < -k::EXP_TH) { i = Is * (k::MIN_EXP - 1.0) + gmin * vb; g = gmin; }
-    else { const double e = exp(t); i = Is * (e - 1.0) + gmin * vb; g = Is * e / Nvtm + gmin; }
+    else { const double e = exp(t); i = Is * (e - 1.0) + gmin * vb; g = Is * e * iN + gmin; }
   } else {
-    const double s = IVjm / Nvtm;
+    const double s = IVjm * iN;
     i = IVjm - Is + s * (vb - vjm) + gmin * vb; g = s + gmin;
   }
 }
@@ -356,118 +379,119 @@ CH_D void junction(double vb, double cz, double czsw, double czswg, double pb, d
                    double mjsw, double mjswg, double& q, double& c) {
   if (vb < 0.0) {
     q = 0.0; c = 0.0;
-    if (cz > 0.0) { const double a = 1.0 - vb / pb, s = exp(-mj * log(a)); q += pb * cz * (1.0 - a * s) / (1.0 - mj); c += cz * s; }
-    if (czsw > 0.0) { const double a = 1.0 - vb / pbsw, s = exp(-mjsw * log(a)); q += pbsw * czsw * (1.0 - a * s) / (1.0 - mjsw); c += czsw * s; }
-    if (czswg > 0.0) { const double a = 1.0 - vb / pbswg, s = exp(-mjswg * log(a)); q += pbswg * czswg * (1.0 - a * s) / (1.0 - mjswg); c += czswg * s; }
+    if (cz > 0.0) { const double a = 1.0 - vb * frcp(pb), s = exp(-mj * log(a)); q += pb * cz * (1.0 - a * s) * frcp(1.0 - mj); c += cz * s; }
+    if (czsw > 0.0) { const double a = 1.0 - vb * frcp(pbsw), s = exp(-mjsw * log(a)); q += pbsw * czsw * (1.0 - a * s) * frcp(1.0 - mjsw); c += czsw * s; }
+    if (czswg > 0.0) { const double a = 1.0 - vb * frcp(pbswg), s = exp(-mjswg * log(a)); q += pbswg * czswg * (1.0 - a * s) * frcp(1.0 - mjswg); c += czswg * s; }
   } else {
-    const double t0 = cz + czsw + czswg, t1 = cz * mj / pb + czsw * mjsw / pbsw + czswg * mjswg / pbswg;
+    const double t0 = cz + czsw + czswg, t1 = cz * mj * frcp(pb) + czsw * mjsw * frcp(pbsw) + czswg * mjswg * frcp(pbswg);
     q = vb * (t0 + 0.5 * t1 * vb); c = t0 + t1 * vb;
   }
 }
 // bias-dependent overlap charge (capMod 2) and capacitance for one side
 CH_D void overlap(double vg, double cov, double clW, double ckappa, double& q, double& c) {
-  const double t0 = vg + 0.02, t1 = sqrt(t0 * t0 + 0.08), t2 = 0.5 * (t0 - t1), dt2 = 0.5 * (1.0 - t0 / t1);
-  const double t4 = sqrt(1.0 - 4.0 * t2 / ckappa);
+  const double t0 = vg + 0.02, t1 = fsqrt(t0 * t0 + 0.08), t2 = 0.5 * (t0 - t1), dt2 = 0.5 * (1.0 - t0 * frcp(t1));
+  const double t4 = fsqrt(1.0 - 4.0 * t2 * frcp(ckappa));
   q = (cov + clW) * vg - clW * (t2 + 0.5 * ckappa * (t4 - 1.0));
-  c = (cov + clW) - clW * (dt2 - dt2 / t4);
+  c = (cov + clW) - clW * (dt2 - dt2 * frcp(t4));
 }
 
-// out[40] = {I[4], Q[4], G[16], C[16]} for terminals (d,g,s,b); multiplier applied by the caller.
-CH_D void b4_device(const B4Col P, double vd, double vg, double vs, double vb, double gmin, double* out) {
+// Mode-frame core: currents into the mode drain / source / bulk and the intrinsic charges, as
+// dual numbers w.r.t. whatever seeds Vgs, Vds, Vbs carry.
+template <int N>
+struct B4Core {
+  DN<N> iD, iS, iB, qd, qg, qs, qb;
+};
+
+template <int N>
+CH_D void b4_core(const B4Col P, const DN<N> Vgs, const DN<N> Vds, const DN<N> Vbs, B4Core<N>& o) {
   using namespace k;
-  const double tp = P[B4I_type];
-  const double vds = tp * (vd - vs), vgs = tp * (vg - vs), vbs = tp * (vb - vs);
-  const bool fwd = vds >= 0.0;
-  // mode-frame independent variables
-  const D3 Vgs{fwd ? vgs : vgs - vds, 1.0, 0.0, 0.0};
-  const D3 Vds{fwd ? vds : -vds, 0.0, 1.0, 0.0};
-  const D3 Vbs{fwd ? vbs : vbs - vds, 0.0, 0.0, 1.0};
+  typedef DN<N> D;
   const double phi = P[B4I_phi], sqrtPhi = P[B4I_sqrtPhi], Vtm = P[B4I_vtm], Leff = P[B4I_leff];
-  const double coxe = P[B4I_coxe], toxe = P[B4I_toxe];
+  const double coxe = P[B4I_coxe], itoxe = frcp(P[B4I_toxe]), icoxe = frcp(coxe), iLeff = frcp(Leff);
 
   // ---- effective body bias ----
-  D3 Vbseff;
+  D Vbseff;
   {
     const double vbsc = P[B4I_vbsc];
-    const D3 t0 = Vbs - (vbsc + 0.001);
-    const D3 t1 = dsqrt(t0 * t0 - 0.004 * vbsc);
+    const D t0 = Vbs - (vbsc + 0.001);
+    const D t1 = dsqrt(t0 * t0 - 0.004 * vbsc);
     if (t0.v >= 0.0) Vbseff = 0.5 * (t0 + t1) + vbsc;
     else Vbseff = vbsc * (1.0 + (-0.002) / (t1 - t0));
     const double t9 = 0.95 * phi;
-    const D3 u0 = t9 - Vbseff - 0.001;
+    const D u0 = t9 - Vbseff - 0.001;
     Vbseff = t9 - 0.5 * (u0 + dsqrt(u0 * u0 + 0.004 * t9));
   }
-  const D3 Phis = phi - Vbseff;
-  const D3 sqrtPhis = dsqrt(Phis);
-  const D3 Xdep = sqrtPhis * (P[B4I_Xdep0] / sqrtPhi);
+  const D Phis = phi - Vbseff;
+  const D sqrtPhis = dsqrt(Phis);
+  const D Xdep = sqrtPhis * (P[B4I_Xdep0] * frcp(sqrtPhi));
 
   // ---- threshold voltage ----
-  const D3 sqXdep = dsqrt(Xdep);
+  const D sqXdep = dsqrt(Xdep);
   const double f1 = P[B4I_factor1], V0 = P[B4I_vbi_phi];
-  auto ltf = [&](double dv2) -> D3 {
-    const D3 a = Vbseff * dv2;
-    const D3 b = (a.v >= -0.5) ? a + 1.0 : (1.0 + 3.0 * a) / (3.0 + 8.0 * a);
+  auto ltf = [&](double dv2) -> D {
+    const D a = Vbseff * dv2;
+    const D b = (a.v >= -0.5) ? a + 1.0 : (1.0 + 3.0 * a) / (3.0 + 8.0 * a);
     return sqXdep * b * f1;
   };
-  const D3 Theta0 = d_sce(P[B4I_dvt1L] / ltf(P[B4I_dvt2]));
-  const D3 Delt_vth = Theta0 * (P[B4I_dvt0] * V0);
+  const D Theta0 = d_sce(P[B4I_dvt1L] / ltf(P[B4I_dvt2]));
+  const D Delt_vth = Theta0 * (P[B4I_dvt0] * V0);
   const double dvt0w = P[B4I_dvt0w];
-  D3 T2w = mk(0.0);
+  D T2w = mkd<N>(0.0);
   if (dvt0w != 0.0) T2w = d_sce(P[B4I_dvt1wWL] / ltf(P[B4I_dvt2w])) * (dvt0w * V0);
-  const D3 T1t = P[B4I_lpe0term] + P[B4I_kt1eff] + Vbseff * P[B4I_kt2t];
-  D3 T3d = P[B4I_eta0] + P[B4I_etab] * Vbseff;
+  const D T1t = P[B4I_lpe0term] + P[B4I_kt1eff] + Vbseff * P[B4I_kt2t];
+  D T3d = P[B4I_eta0] + P[B4I_etab] * Vbseff;
   if (T3d.v < 1.0e-4) T3d = (2.0e-4 - T3d) / (3.0 - 2.0e4 * T3d);
-  const D3 DIBL_Sft = T3d * Vds * P[B4I_theta0vb0];
+  const D DIBL_Sft = T3d * Vds * P[B4I_theta0vb0];
   const double vthNW = P[B4I_vthNarrowW], LpeVb = P[B4I_LpeVb], k1ox = P[B4I_k1ox], k2ox = P[B4I_k2ox];
-  D3 Vth = P[B4I_vth0t] + (k1ox * sqrtPhis - P[B4I_k1] * sqrtPhi) * LpeVb - k2ox * Vbseff - Delt_vth - T2w +
-           (P[B4I_k3] + P[B4I_k3b] * Vbseff) * vthNW + T1t - DIBL_Sft;
+  D Vth = P[B4I_vth0t] + (k1ox * sqrtPhis - P[B4I_k1] * sqrtPhi) * LpeVb - k2ox * Vbseff - Delt_vth - T2w +
+          (P[B4I_k3] + P[B4I_k3b] * Vbseff) * vthNW + T1t - DIBL_Sft;
 
   // ---- subthreshold swing ----
-  D3 n;
+  D n;
   {
-    const D3 c1 = EPSSI / Xdep;
-    const D3 t4 = (P[B4I_nfactor] * c1 + (P[B4I_cdsc] + P[B4I_cdscb] * Vbseff + P[B4I_cdscd] * Vds) * Theta0 + P[B4I_cit]) / coxe;
+    const D c1 = EPSSI / Xdep;
+    const D t4 = (P[B4I_nfactor] * c1 + (P[B4I_cdsc] + P[B4I_cdscb] * Vbseff + P[B4I_cdscd] * Vds) * Theta0 + P[B4I_cit]) * icoxe;
     n = (t4.v >= -0.5) ? t4 + 1.0 : (1.0 + 3.0 * t4) / (3.0 + 8.0 * t4);
   }
   {
     const double dvtp0 = P[B4I_dvtp0];
     if (dvtp0 > 0.0) {
-      const D3 t0 = -P[B4I_dvtp1] * Vds;
-      const D3 t2 = (t0.v < -EXP_TH) ? mk(MIN_EXP) : dexp(t0);
-      const D3 t3 = Leff + dvtp0 * (1.0 + t2);
+      const D t0 = -P[B4I_dvtp1] * Vds;
+      const D t2 = (t0.v < -EXP_TH) ? mkd<N>(MIN_EXP) : dexp(t0);
+      const D t3 = Leff + dvtp0 * (1.0 + t2);
       Vth = Vth - n * (Vtm * dlog(Leff / t3));
     }
   }
   // ---- poly depletion ----
-  D3 Vgs_eff = Vgs;
+  D Vgs_eff = Vgs;
   {
     const double ngate = P[B4I_ngate], vfbphi = P[B4I_vfb_phi];
     if (ngate > 1.0e18 && ngate < 1.0e25 && Vgs.v > vfbphi) {
-      const double T1p = P[B4I_polyT1];
-      const D3 t8 = Vgs - vfbphi;
-      const D3 t4 = dsqrt(1.0 + t8 * (2.0 / T1p));
-      const D3 t2 = 2.0 * t8 / (t4 + 1.0);
-      const D3 t3 = t2 * t2 * (0.5 / T1p);
-      const D3 t7 = 1.07 - t3;
-      const D3 t6 = dsqrt(t7 * t7 + 0.224);
+      const double iT1p = frcp(P[B4I_polyT1]);
+      const D t8 = Vgs - vfbphi;
+      const D t4 = dsqrt(1.0 + t8 * (2.0 * iT1p));
+      const D t2 = 2.0 * t8 / (t4 + 1.0);
+      const D t3 = t2 * t2 * (0.5 * iT1p);
+      const D t7 = 1.07 - t3;
+      const D t6 = dsqrt(t7 * t7 + 0.224);
       Vgs_eff = Vgs - (1.12 - 0.5 * (t7 + t6));
     }
   }
-  const D3 Vgst = Vgs_eff - Vth;
+  const D Vgst = Vgs_eff - Vth;
 
   // ---- Vgsteff ----
-  D3 Vgsteff;
+  D Vgsteff;
+  const D inVt = recip(n * Vtm);
   {
-    const double mstar = P[B4I_mstar], cc = coxe / P[B4I_cdep0];
-    const D3 nVt = n * Vtm;
-    const D3 t1 = mstar * Vgst;
-    const D3 t2 = t1 / nVt;
-    D3 t10;
+    const double mstar = P[B4I_mstar], cc = coxe * frcp(P[B4I_cdep0]);
+    const D t1 = mstar * Vgst;
+    const D t2 = t1 * inVt;
+    D t10;
     if (t2.v > EXP_TH) t10 = t1;
     else if (t2.v < -EXP_TH) t10 = n * (Vtm * log(1.0 + MIN_EXP));
-    else t10 = nVt * dlog(1.0 + dexp(t2));
-    const D3 h2 = (P[B4I_voffcbn] - (1.0 - mstar) * Vgst) / nVt;
-    D3 t9;
+    else t10 = (n * Vtm) * dlog(1.0 + dexp(t2));
+    const D h2 = (P[B4I_voffcbn] - (1.0 - mstar) * Vgst) * inVt;
+    D t9;
     if (h2.v < -EXP_TH) t9 = mstar + n * (cc * MIN_EXP);
     else if (h2.v > EXP_TH) t9 = mstar + n * (cc * MAX_EXP);
     else t9 = mstar + n * (cc * dexp(h2));
@@ -475,301 +499,364 @@ CH_D void b4_device(const B4Col P, double vd, double vg, double vs, double vb, d
   }
 
   // ---- Weff, Rds ----
-  const D3 dsp = sqrtPhis - sqrtPhi;
-  D3 Weff = P[B4I_weff] - 2.0 * (P[B4I_dwg] * Vgsteff + P[B4I_dwb] * dsp);
+  const D dsp = sqrtPhis - sqrtPhi;
+  D Weff = P[B4I_weff] - 2.0 * (P[B4I_dwg] * Vgsteff + P[B4I_dwb] * dsp);
   if (Weff.v < 2.0e-8) Weff = 2.0e-8 * (4.0e-8 - Weff) / (6.0e-8 - 2.0 * Weff);
-  D3 Rds;
+  D Rds;
   {
-    const D3 t2 = 1.0 / (1.0 + P[B4I_prwg] * Vgsteff) + P[B4I_prwb] * dsp;
+    const D t2 = recip(1.0 + P[B4I_prwg] * Vgsteff) + P[B4I_prwb] * dsp;
     Rds = P[B4I_rdswmin] + (t2 + dsqrt(t2 * t2 + 0.01)) * P[B4I_rds0h];
   }
   // ---- Abulk ----
-  D3 Abulk0, Abulk;
+  D Abulk0, Abulk;
   {
-    const D3 t1 = (0.5 * k1ox * LpeVb) / sqrtPhis + (k2ox - P[B4I_k3b] * vthNW);
-    const D3 t5 = Leff / (Leff + 2.0 * dsqrt(P[B4I_xj] * Xdep));
-    const D3 t2 = P[B4I_a0] * t5 + P[B4I_b0term];
+    const D t1 = (0.5 * k1ox * LpeVb) / sqrtPhis + (k2ox - P[B4I_k3b] * vthNW);
+    const D t5 = Leff / (Leff + 2.0 * dsqrt(P[B4I_xj] * Xdep));
+    const D t2 = P[B4I_a0] * t5 + P[B4I_b0term];
     Abulk0 = 1.0 + t1 * t2;
-    const D3 dAdVg = -t1 * (P[B4I_agsa0] * (t5 * t5 * t5));
+    const D dAdVg = -t1 * (P[B4I_agsa0] * (t5 * t5 * t5));
     Abulk = Abulk0 + dAdVg * Vgsteff;
     if (Abulk0.v < 0.1) Abulk0 = (0.2 - Abulk0) / (3.0 - 20.0 * Abulk0);
     if (Abulk.v < 0.1) Abulk = (0.2 - Abulk) / (3.0 - 20.0 * Abulk);
-    const D3 t2k = P[B4I_keta] * Vbseff;
-    const D3 t0k = (t2k.v >= -0.9) ? recip(1.0 + t2k) : (17.0 + 20.0 * t2k) / (0.8 + t2k);
+    const D t2k = P[B4I_keta] * Vbseff;
+    const D t0k = (t2k.v >= -0.9) ? recip(1.0 + t2k) : (17.0 + 20.0 * t2k) / (0.8 + t2k);
     Abulk = Abulk * t0k;
     Abulk0 = Abulk0 * t0k;
   }
   // ---- mobility ----
-  D3 ueff;
+  D iueff;  // 1/ueff
   {
     const int mobmod = (int)P[B4I_mobmod];
-    D3 t5;
+    D t5;
     if (mobmod == 0) {
-      const D3 t3 = (Vgsteff + Vth + Vth) / toxe;
+      const D t3 = (Vgsteff + Vth + Vth) * itoxe;
       t5 = t3 * (P[B4I_ua] + P[B4I_uc] * Vbseff + P[B4I_ub] * t3);
     } else if (mobmod == 1) {
-      const D3 t3 = (Vgsteff + Vth + Vth) / toxe;
+      const D t3 = (Vgsteff + Vth + Vth) * itoxe;
       t5 = t3 * (P[B4I_ua] + P[B4I_ub] * t3) * (1.0 + P[B4I_uc] * Vbseff);
     } else {
-      const D3 t0 = (Vgsteff + P[B4I_vtfbphi1]) / toxe;
+      const D t0 = (Vgsteff + P[B4I_vtfbphi1]) * itoxe;
       t5 = dexp(P[B4I_eu] * dlog(t0)) * (P[B4I_ua] + P[B4I_uc] * Vbseff);
     }
-    const D3 den = (t5.v >= -0.8) ? t5 + 1.0 : (0.6 + t5) / (7.0 + 10.0 * t5);
-    ueff = P[B4I_u0temp] / den;
+    const D den = (t5.v >= -0.8) ? t5 + 1.0 : (0.6 + t5) / (7.0 + 10.0 * t5);
+    iueff = den * frcp(P[B4I_u0temp]);
   }
+  const D ueff = recip(iueff);
   // ---- Vdsat ----
   const double vsat = P[B4I_vsattemp];
-  const D3 WVCoxRds = Weff * Rds * (vsat * coxe);
-  const D3 Esat = (2.0 * vsat) / ueff;
-  const D3 EsatL = Esat * Leff;
-  D3 Lambda;
+  const D WVCoxRds = Weff * Rds * (vsat * coxe);
+  const D Esat = (2.0 * vsat) * iueff;
+  const D EsatL = Esat * Leff;
+  const D iEsatL = recip(EsatL);
+  D Lambda;
   {
     const double a1 = P[B4I_a1], a2 = P[B4I_a2];
-    if (a1 == 0.0) Lambda = mk(a2);
+    if (a1 == 0.0) Lambda = mkd<N>(a2);
     else if (a1 > 0.0) {
       const double t0 = 1.0 - a2;
-      const D3 t1 = t0 - a1 * Vgsteff - 0.0001;
+      const D t1 = t0 - a1 * Vgsteff - 0.0001;
       Lambda = a2 + t0 - 0.5 * (t1 + dsqrt(t1 * t1 + 0.0004 * t0));
     } else {
-      const D3 t1 = a2 + a1 * Vgsteff - 0.0001;
+      const D t1 = a2 + a1 * Vgsteff - 0.0001;
       Lambda = 0.5 * (t1 + dsqrt(t1 * t1 + 0.0004 * a2));
     }
   }
-  const D3 Vgst2Vtm = Vgsteff + 2.0 * Vtm;
-  D3 Vdsat;
+  const D iLam = recip(Lambda);
+  const D Vgst2Vtm = Vgsteff + 2.0 * Vtm;
+  const D iVgst2Vtm = recip(Vgst2Vtm);
+  D Vdsat;
   if (Rds.v == 0.0 && Lambda.v == 1.0) Vdsat = EsatL * Vgst2Vtm / (Abulk * EsatL + Vgst2Vtm);
   else {
-    const D3 iL = recip(Lambda);
-    const D3 t9 = Abulk * WVCoxRds;
-    const D3 t0 = 2.0 * Abulk * (t9 - 1.0 + iL);
-    const D3 t1 = Vgst2Vtm * (2.0 * iL - 1.0) + Abulk * EsatL + 3.0 * (Vgst2Vtm * t9);
-    const D3 t2 = Vgst2Vtm * (EsatL + 2.0 * (Vgst2Vtm * WVCoxRds));
+    const D t9 = Abulk * WVCoxRds;
+    const D t0 = 2.0 * Abulk * (t9 - 1.0 + iLam);
+    const D t1 = Vgst2Vtm * (2.0 * iLam - 1.0) + Abulk * EsatL + 3.0 * (Vgst2Vtm * t9);
+    const D t2 = Vgst2Vtm * (EsatL + 2.0 * (Vgst2Vtm * WVCoxRds));
     Vdsat = (t1 - dsqrt(t1 * t1 - 2.0 * t0 * t2)) / t0;
   }
   // ---- Vdseff ----
-  D3 Vdseff;
+  D Vdseff;
   {
     const double delta = P[B4I_delta];
-    const D3 t1 = Vdsat - Vds - delta;
-    const D3 t2 = dsqrt(t1 * t1 + 4.0 * delta * Vdsat);
+    const D t1 = Vdsat - Vds - delta;
+    const D t2 = dsqrt(t1 * t1 + 4.0 * delta * Vdsat);
     if (t1.v >= 0.0) Vdseff = Vdsat - 0.5 * (t1 + t2);
     else Vdseff = Vdsat * (1.0 - (2.0 * delta) / (t2 - t1));
     if (Vds.v == 0.0) Vdseff = Vds;
     if (Vdseff.v > Vds.v) Vdseff = Vds;
   }
-  const D3 diffVds = Vds - Vdseff;
+  const D diffVds = Vds - Vdseff;
   // ---- Vasat ----
-  const D3 iLam2 = 2.0 / Lambda - 1.0;
-  const D3 Vasat = (EsatL + Vdsat + 2.0 * (WVCoxRds * Vgsteff) * (1.0 - 0.5 * Abulk * Vdsat / Vgst2Vtm)) / (iLam2 + WVCoxRds * Abulk);
+  const D Vasat = (EsatL + Vdsat + 2.0 * (WVCoxRds * Vgsteff) * (1.0 - 0.5 * Abulk * Vdsat * iVgst2Vtm)) / ((2.0 * iLam - 1.0) + WVCoxRds * Abulk);
   // ---- channel conductance ----
-  D3 Idl;
+  D Idl;
   {
-    const D3 t0 = (Vgsteff + P[B4I_vtfbphi2]) / (2.0 * P[B4I_toxp8]);
-    const D3 Tcen = 1.9e-9 / (1.0 + dexp(0.7 * dlog(t0)));
+    const D t0 = (Vgsteff + P[B4I_vtfbphi2]) * (0.5 * frcp(P[B4I_toxp8]));
+    const D Tcen = 1.9e-9 / (1.0 + dexp(0.7 * dlog(t0)));
     const double coxp = P[B4I_coxp];
-    const D3 Coxeff = (EPSSI * coxp) / (EPSSI + coxp * Tcen);
-    const D3 beta = ueff * Coxeff * Weff / Leff;
-    const D3 fg1 = Vgsteff * (1.0 - 0.5 * Vdseff * Abulk / Vgst2Vtm);
-    const D3 gche = beta * fg1 / (1.0 + Vdseff / EsatL);
+    const D Coxeff = (EPSSI * coxp) / (EPSSI + coxp * Tcen);
+    const D beta = ueff * Coxeff * Weff * iLeff;
+    const D fg1 = Vgsteff * (1.0 - 0.5 * Vdseff * Abulk * iVgst2Vtm);
+    const D gche = beta * fg1 / (1.0 + Vdseff * iEsatL);
     Idl = gche / (1.0 + gche * Rds);
   }
   // ---- output resistance ----
   const double fpL = P[B4I_fproutL];
-  const D3 FP = (fpL <= 0.0) ? mk(1.0) : recip(1.0 + fpL / Vgst2Vtm);
-  D3 Pvag;
+  const D FP = (fpL <= 0.0) ? mkd<N>(1.0) : recip(1.0 + fpL * iVgst2Vtm);
+  D Pvag;
   {
-    const D3 t9 = (P[B4I_pvag] / EsatL) * Vgsteff;
+    const D t9 = (P[B4I_pvag] * iEsatL) * Vgsteff;
     Pvag = (t9.v > -0.9) ? t9 + 1.0 : (0.8 + t9) / (17.0 + 20.0 * t9);
   }
-  D3 Cclm, VACLM;
+  D iCclm, VACLM;  // 1/Cclm
   {
     const double pl = P[B4I_pclmlitl];
     if (pl > 0.0 && diffVds.v > 1.0e-10) {
-      Cclm = FP * Pvag * (1.0 + Rds * Idl) * (Leff + Vdsat / Esat) / pl;
+      const D Cclm = FP * Pvag * (1.0 + Rds * Idl) * (Leff + Vdsat * ueff * (0.5 * frcp(vsat))) * frcp(pl);
+      iCclm = recip(Cclm);
       VACLM = Cclm * diffVds;
-    } else { Cclm = mk(MAX_EXP); VACLM = mk(MAX_EXP); }
+    } else { iCclm = mkd<N>(1.0 / MAX_EXP); VACLM = mkd<N>(MAX_EXP); }
   }
-  D3 VADIBL;
+  D iVADIBL;
   {
     const double th = P[B4I_thetaRout];
     if (th > MIN_EXP) {
-      const D3 t8 = Abulk * Vdsat;
-      VADIBL = (Vgst2Vtm - Vgst2Vtm * t8 / (Vgst2Vtm + t8)) / th;
-      const D3 t7 = P[B4I_pdiblb] * Vbseff;
-      VADIBL = VADIBL * ((t7.v >= -0.9) ? recip(1.0 + t7) : (17.0 + 20.0 * t7) / (0.8 + t7));
-      VADIBL = VADIBL * Pvag;
-    } else VADIBL = mk(MAX_EXP);
+      const D t8 = Abulk * Vdsat;
+      D va = (Vgst2Vtm - Vgst2Vtm * t8 / (Vgst2Vtm + t8)) * frcp(th);
+      const D t7 = P[B4I_pdiblb] * Vbseff;
+      va = va * ((t7.v >= -0.9) ? recip(1.0 + t7) : (17.0 + 20.0 * t7) / (0.8 + t7));
+      iVADIBL = recip(va * Pvag);
+    } else iVADIBL = mkd<N>(1.0 / MAX_EXP);
   }
-  D3 VADITS;
+  D iVADITS;
   {
     const double pdits = P[B4I_pdits];
     if (pdits > MIN_EXP) {
-      const D3 t0 = P[B4I_pditsd] * Vds;
-      const D3 t1 = (t0.v > EXP_TH) ? mk(MAX_EXP) : dexp(t0);
-      VADITS = (1.0 + P[B4I_pditslL] * t1) / pdits * FP;
-    } else VADITS = mk(MAX_EXP);
+      const D t0 = P[B4I_pditsd] * Vds;
+      const D t1 = (t0.v > EXP_TH) ? mkd<N>(MAX_EXP) : dexp(t0);
+      iVADITS = recip((1.0 + P[B4I_pditslL] * t1) * frcp(pdits) * FP);
+    } else iVADITS = mkd<N>(1.0 / MAX_EXP);
   }
-  D3 VASCBE;
+  D iVASCBE;
   {
     const double ps2 = P[B4I_pscbe2], ps1l = P[B4I_pscbe1l];
     if (ps2 > 0.0) {
-      if (diffVds.v > ps1l / EXP_TH) VASCBE = Leff * dexp(ps1l / diffVds) / ps2;
-      else VASCBE = mk(MAX_EXP * Leff / ps2);
-    } else VASCBE = mk(MAX_EXP);
+      if (diffVds.v > ps1l / EXP_TH) iVASCBE = (ps2 * iLeff) * dexp(-ps1l / diffVds);
+      else iVASCBE = mkd<N>(ps2 * iLeff / MAX_EXP);
+    } else iVASCBE = mkd<N>(1.0 / MAX_EXP);
   }
-  D3 Idsa = Idl * (1.0 + diffVds / VADIBL);
-  Idsa = Idsa * (1.0 + diffVds / VADITS);
-  Idsa = Idsa * (1.0 + dlog((Vasat + VACLM) / Vasat) / Cclm);
-  D3 Isub = mk(0.0);
+  D Idsa = Idl * (1.0 + diffVds * iVADIBL);
+  Idsa = Idsa * (1.0 + diffVds * iVADITS);
+  Idsa = Idsa * (1.0 + dlog((Vasat + VACLM) / Vasat) * iCclm);
+  D Isub = mkd<N>(0.0);
   {
     const double aL = P[B4I_alphaL], beta0 = P[B4I_beta0];
     if (aL > 0.0 && beta0 > 0.0) {
-      D3 t1;
+      D t1;
       if (diffVds.v > beta0 / EXP_TH) t1 = aL * diffVds * dexp(-beta0 / diffVds);
       else t1 = (aL * MIN_EXP) * diffVds;
       Isub = t1 * (Idsa * Vdseff);
     }
   }
   const double nf = P[B4I_nf];
-  const D3 Ids = Idsa * (1.0 + diffVds / VASCBE) * Vdseff * nf;
+  const D Ids = Idsa * (1.0 + diffVds * iVASCBE) * Vdseff * nf;
   Isub = Isub * nf;
   // ---- GIDL / GISL ----
-  D3 Igidl = mk(0.0), Igisl = mk(0.0);
+  D Igidl = mkd<N>(0.0), Igisl = mkd<N>(0.0);
   {
     const double agW = P[B4I_agidlW];
     if (agW > 0.0) {
-      const double bg = P[B4I_bgidl], cg = P[B4I_cgidl], eg = P[B4I_egidl], t3x = P[B4I_toxe3];
-      const D3 Vbd = Vbs - Vds;
-      const D3 t1 = (Vds - Vgs_eff - eg) / t3x;
+      const double bg = P[B4I_bgidl], cg = P[B4I_cgidl], eg = P[B4I_egidl], it3x = frcp(P[B4I_toxe3]);
+      const D Vbd = Vbs - Vds;
+      const D t1 = (Vds - Vgs_eff - eg) * it3x;
       if (t1.v > 0.0 && Vbd.v <= 0.0) {
-        const D3 t2 = bg / t1;
-        const D3 ig = (t2.v < 100.0) ? agW * t1 * dexp(-t2) : (agW * 3.720075976e-44) * t1;
-        const D3 t5 = -Vbd * Vbd * Vbd;
+        const D t2 = bg / t1;
+        const D ig = (t2.v < 100.0) ? agW * t1 * dexp(-t2) : (agW * 3.720075976e-44) * t1;
+        const D t5 = -Vbd * Vbd * Vbd;
         Igidl = ig * (t5 / (cg + t5));
       }
-      const D3 s1 = (-Vgs_eff - eg) / t3x;
+      const D s1 = (-Vgs_eff - eg) * it3x;
       if (s1.v > 0.0 && Vbs.v <= 0.0) {
-        const D3 t2 = bg / s1;
-        const D3 ig = (t2.v < 100.0) ? agW * s1 * dexp(-t2) : (agW * 3.720075976e-44) * s1;
-        const D3 t5 = -Vbs * Vbs * Vbs;
+        const D t2 = bg / s1;
+        const D ig = (t2.v < 100.0) ? agW * s1 * dexp(-t2) : (agW * 3.720075976e-44) * s1;
+        const D t5 = -Vbs * Vbs * Vbs;
         Igisl = ig * (t5 / (cg + t5));
       }
     }
   }
   // ---- intrinsic charges (capMod 2) ----
-  D3 qg = mk(0.0), qb = mk(0.0), qsm = mk(0.0), qdm = mk(0.0);
+  D qg = mkd<N>(0.0), qb = mkd<N>(0.0), qsm = mkd<N>(0.0), qdm = mkd<N>(0.0);
   const double xpart = P[B4I_xpart];
   if (xpart >= 0.0 && (int)P[B4I_capmod] != 0) {
-    const D3 VbseffCV = (Vbseff.v < 0.0) ? Vbseff : phi - Phis;
+    const D VbseffCV = (Vbseff.v < 0.0) ? Vbseff : phi - Phis;
     const double CoxWL = P[B4I_CoxWL], vfbzb = P[B4I_vfbzb], Cox = P[B4I_coxp], Tox = P[B4I_toxp8], ldeb = P[B4I_ldeb];
-    const D3 T0q = n * (Vtm * P[B4I_noff]);
-    const D3 T1q = (Vgst - P[B4I_voffcv]) / T0q;
-    D3 Vgc;
+    const double iTox = frcp(Tox), cwl = CoxWL * icoxe;
+    const D T0q = n * (Vtm * P[B4I_noff]);
+    const D T1q = (Vgst - P[B4I_voffcv]) / T0q;
+    D Vgc;
     if (T1q.v > EXP_TH) Vgc = Vgst - P[B4I_voffcv];
     else if (T1q.v < -EXP_TH) Vgc = T0q * log(1.0 + MIN_EXP);
     else Vgc = T0q * dlog(1.0 + dexp(T1q));
-    const D3 V3 = vfbzb - Vgs_eff + VbseffCV - 0.02;
-    const D3 Vfbeff = vfbzb - 0.5 * (V3 + dsqrt(V3 * V3 + ((vfbzb <= 0.0) ? -0.08 * vfbzb : 0.08 * vfbzb)));
-    const D3 tm = (Vgs_eff - VbseffCV - vfbzb) * (P[B4I_acde] / Tox);
-    D3 Tcen;
+    const D V3 = vfbzb - Vgs_eff + VbseffCV - 0.02;
+    const D Vfbeff = vfbzb - 0.5 * (V3 + dsqrt(V3 * V3 + ((vfbzb <= 0.0) ? -0.08 * vfbzb : 0.08 * vfbzb)));
+    const D tm = (Vgs_eff - VbseffCV - vfbzb) * (P[B4I_acde] * iTox);
+    D Tcen;
     if (tm.v > -EXP_TH && tm.v < EXP_TH) Tcen = ldeb * dexp(tm);
-    else Tcen = mk(tm.v <= -EXP_TH ? ldeb * MIN_EXP : ldeb * MAX_EXP);
+    else Tcen = mkd<N>(tm.v <= -EXP_TH ? ldeb * MIN_EXP : ldeb * MAX_EXP);
     const double LINK = 1.0e-11 * Tox;  // 1e-3 * toxp
-    const D3 V3c = ldeb - Tcen - LINK;
+    const D V3c = ldeb - Tcen - LINK;
     Tcen = ldeb - 0.5 * (V3c + dsqrt(V3c * V3c + 4.0 * LINK * ldeb));
-    D3 Ccen = EPSSI / Tcen;
-    D3 Coxeff = Ccen * Cox / (Cox + Ccen);
-    D3 CoxWLcen = Coxeff * (CoxWL / coxe);
-    const D3 Qac0 = CoxWLcen * (Vfbeff - vfbzb);
+    // Coxeff = Cox*Ccen/(Cox+Ccen) with Ccen = EPSSI/Tcen  =  Cox*EPSSI/(Cox*Tcen + EPSSI)
+    D CoxWLcen = (Cox * EPSSI * cwl) / (Cox * Tcen + EPSSI);
+    const D Qac0 = CoxWLcen * (Vfbeff - vfbzb);
     const double h0 = 0.5 * k1ox;
-    const D3 T3s = Vgs_eff - Vfbeff - VbseffCV - Vgc;
-    D3 T1s;
-    if (k1ox == 0.0) T1s = mk(0.0);
-    else if (T3s.v < 0.0) T1s = h0 + T3s / k1ox;
+    const D T3s = Vgs_eff - Vfbeff - VbseffCV - Vgc;
+    D T1s;
+    if (k1ox == 0.0) T1s = mkd<N>(0.0);
+    else if (T3s.v < 0.0) T1s = h0 + T3s * frcp(k1ox);
     else T1s = dsqrt(h0 * h0 + T3s);
-    const D3 Qsub0 = CoxWLcen * (k1ox * (T1s - h0));
+    const D Qsub0 = CoxWLcen * (k1ox * (T1s - h0));
     double Den, T0d;
     if (k1ox <= 0.0) { Den = 0.25 * P[B4I_moinVtm]; T0d = 0.5 * sqrtPhi; }
     else { Den = P[B4I_moinVtm] * k1ox * k1ox; T0d = k1ox * sqrtPhi; }
-    const D3 DeltaPhi = Vtm * dlog(1.0 + (2.0 * T0d + Vgc) * Vgc / Den);
-    const D3 T3t = 4.0 * (Vth - vfbzb - phi);
-    const D3 T0t = ((T3t.v >= 0.0) ? Vgc + T3t : Vgc + 1.0e-20) / (2.0 * Tox);
+    const D DeltaPhi = Vtm * dlog(1.0 + (2.0 * T0d + Vgc) * Vgc * frcp(Den));
+    const D T3t = 4.0 * (Vth - vfbzb - phi);
+    const D T0t = ((T3t.v >= 0.0) ? Vgc + T3t : Vgc + 1.0e-20) * (0.5 * iTox);
     Tcen = 1.9e-9 / (1.0 + dexp(0.7 * dlog(T0t)));
-    Ccen = EPSSI / Tcen;
-    Coxeff = Ccen * Cox / (Cox + Ccen);
-    CoxWLcen = Coxeff * (CoxWL / coxe);
-    const D3 AbulkCV = Abulk0 * P[B4I_abulkCVfactor];
-    const D3 T1 = Vgc - DeltaPhi;
-    const D3 VdsatCV = T1 / AbulkCV;
-    const D3 T0v = VdsatCV - Vds - 0.02;
-    const D3 T1v = dsqrt(T0v * T0v + 0.08 * VdsatCV);
-    D3 VdseffCV;
+    CoxWLcen = (Cox * EPSSI * cwl) / (Cox * Tcen + EPSSI);
+    const D AbulkCV = Abulk0 * P[B4I_abulkCVfactor];
+    const D T1 = Vgc - DeltaPhi;
+    const D VdsatCV = T1 / AbulkCV;
+    const D T0v = VdsatCV - Vds - 0.02;
+    const D T1v = dsqrt(T0v * T0v + 0.08 * VdsatCV);
+    D VdseffCV;
     if (T0v.v >= 0.0) VdseffCV = VdsatCV - 0.5 * (T0v + T1v);
     else VdseffCV = VdsatCV * (1.0 - 0.04 / (T1v - T0v));
     if (Vds.v == 0.0) VdseffCV = Vds;
-    const D3 T0 = AbulkCV * VdseffCV;
-    const D3 T2 = 12.0 * (T1 - 0.5 * T0 + 1.0e-20);
-    const D3 T3 = T0 / T2;
+    const D T0 = AbulkCV * VdseffCV;
+    const D T2 = 12.0 * (T1 - 0.5 * T0 + 1.0e-20);
+    const D iT2 = recip(T2);
+    const D T3 = T0 * iT2;
     qg = CoxWLcen * (T1 - T0 * (0.5 - T3));
-    qb = CoxWLcen * (1.0 - AbulkCV) * (0.5 * VdseffCV - T0 * VdseffCV / T2);
-    if (xpart > 0.5) qsm = -CoxWLcen * (0.5 * T1 + 0.25 * T0 - 0.5 * T0 * T0 / T2);
+    qb = CoxWLcen * (1.0 - AbulkCV) * (0.5 * VdseffCV - T3 * VdseffCV);
+    if (xpart > 0.5) qsm = -CoxWLcen * (0.5 * T1 + 0.25 * T0 - 0.5 * T0 * T3);
     else if (xpart < 0.5) {
-      const D3 T2b = T2 / 12.0;
-      const D3 T4b = T1 * ((2.0 / 3.0) * T0 * T0 + T1 * (T1 - (4.0 / 3.0) * T0)) - (2.0 / 15.0) * T0 * T0 * T0;
-      qsm = -(0.5 * CoxWLcen / (T2b * T2b)) * T4b;
+      const D T4b = T1 * ((2.0 / 3.0) * T0 * T0 + T1 * (T1 - (4.0 / 3.0) * T0)) - (2.0 / 15.0) * T0 * T0 * T0;
+      qsm = -(72.0 * CoxWLcen * (iT2 * iT2)) * T4b;  // 0.5/(T2/12)^2 = 72/T2^2
     } else qsm = -0.5 * qg;
     qg = qg + Qac0 + Qsub0 - qb;
     qb = qb - (Qac0 + Qsub0);
     qdm = -(qg + qb + qsm);
   }
-
-  // ---- assemble the mode-frame stamp: terminals (D', G, S', B) ----
   // currents into the device: D': Ids + Isub + Igidl ; S': -Ids + Igisl ; B: -Isub - Igidl - Igisl
-  const D3 iD = Ids + Isub + Igidl, iS = Igisl - Ids, iB = -(Isub + Igidl + Igisl);
-  // column order of partials in the mode frame: (D', G, S', B); d/dS' = -(g+d+b)
+  o.iD = Ids + Isub + Igidl; o.iS = Igisl - Ids; o.iB = -(Isub + Igidl + Igisl);
+  o.qd = qdm; o.qg = qg; o.qs = qsm; o.qb = qb;
+}
+
+// Junction diodes, junction charges and overlap charges on the TRUE terminals (type-normalised
+// voltages): 5 two-terminal elements (a, b, value x, derivative dx w.r.t. v_a - v_b).
+struct B4Two {
+  double ibs, gbs, ibd, gbd, qbs, cbs, qbd, cbd, qgd, cgd, qgs, cgs, qgb, cgb;
+};
+CH_D void b4_two_terminal(const B4Col P, double vgs, double vds, double vbs, double gmin, B4Two& t) {
+  const double vbd = vbs - vds;
+  diode(vbs, P[B4I_Isbs], P[B4I_Nvtms], P[B4I_vjsmFwd], P[B4I_IVjsmFwd], gmin, t.ibs, t.gbs);
+  diode(vbd, P[B4I_Isbd], P[B4I_Nvtmd], P[B4I_vjdmFwd], P[B4I_IVjdmFwd], gmin, t.ibd, t.gbd);
+  junction(vbs, P[B4I_czbs], P[B4I_czbssw], P[B4I_czbsswg], P[B4I_PhiBS], P[B4I_PhiBSWS], P[B4I_PhiBSWGS], P[B4I_mjs], P[B4I_mjsws], P[B4I_mjswgs], t.qbs, t.cbs);
+  junction(vbd, P[B4I_czbd], P[B4I_czbdsw], P[B4I_czbdswg], P[B4I_PhiBD], P[B4I_PhiBSWD], P[B4I_PhiBSWGD], P[B4I_mjd], P[B4I_mjswd], P[B4I_mjswgd], t.qbd, t.cbd);
+  if ((int)P[B4I_capmod] != 0) {
+    overlap(vgs - vds, P[B4I_cgdo], P[B4I_cgdlW], P[B4I_ckappad], t.qgd, t.cgd);
+    overlap(vgs, P[B4I_cgso], P[B4I_cgslW], P[B4I_ckappas], t.qgs, t.cgs);
+    t.cgb = P[B4I_cgbo]; t.qgb = t.cgb * (vgs - vbs);
+  } else { t.qgd = t.cgd = t.qgs = t.cgs = t.qgb = t.cgb = 0.0; }
+}
+
+// One lane per instance.  out[40] = {I[4], Q[4], G[16], C[16]} for terminals (d,g,s,b);
+// the multiplier is applied by the caller.
+CH_D void b4_device(const B4Col P, double vd, double vg, double vs, double vb, double gmin, double* out) {
+  const double tp = P[B4I_type];
+  const double vds = tp * (vd - vs), vgs = tp * (vg - vs), vbs = tp * (vb - vs);
+  const bool fwd = vds >= 0.0;
+  typedef DN<3> D3;
+  D3 Vgs = mkd<3>(fwd ? vgs : vgs - vds), Vds = mkd<3>(fwd ? vds : -vds), Vbs = mkd<3>(fwd ? vbs : vbs - vds);
+  Vgs.p[0] = 1.0; Vds.p[1] = 1.0; Vbs.p[2] = 1.0;
+  B4Core<3> c;
+  b4_core<3>(P, Vgs, Vds, Vbs, c);
   double* I = out; double* Qo = out + 4; double* G = out + 8; double* C = out + 24;
+  // mode-frame stamp, rows/cols (D', G, S', B); d/dS' = -(sum of the three partials)
   auto put = [&](int row, const D3& x, double* val, double* M) {
-    val[row] = x.v; M[row * 4 + 0] = x.d; M[row * 4 + 1] = x.g; M[row * 4 + 3] = x.b; M[row * 4 + 2] = -(x.g + x.d + x.b);
+    val[row] = x.v; M[row * 4 + 0] = x.p[1]; M[row * 4 + 1] = x.p[0]; M[row * 4 + 3] = x.p[2]; M[row * 4 + 2] = -(x.p[0] + x.p[1] + x.p[2]);
   };
-  // rows in mode frame: 0=D', 1=G, 2=S', 3=B
-  put(0, iD, I, G); put(1, mk(0.0), I, G); put(2, iS, I, G); put(3, iB, I, G);
-  put(0, qdm, Qo, C); put(1, qg, Qo, C); put(2, qsm, Qo, C); put(3, qb, Qo, C);
+  put(0, c.iD, I, G); put(1, mkd<3>(0.0), I, G); put(2, c.iS, I, G); put(3, c.iB, I, G);
+  put(0, c.qd, Qo, C); put(1, c.qg, Qo, C); put(2, c.qs, Qo, C); put(3, c.qb, Qo, C);
   // map mode frame -> true (d,g,s,b): exchange index 0 and 2 (rows and columns) when reversed.
   // Static indices under one runtime predicate keep everything in registers (no scratch).
   if (!fwd) {
     auto sw = [](double& x, double& y) { const double t = x; x = y; y = t; };
     sw(I[0], I[2]); sw(Qo[0], Qo[2]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { sw(G[0 * 4 + c], G[2 * 4 + c]); sw(C[0 * 4 + c], C[2 * 4 + c]); }
+    for (int cc = 0; cc < 4; ++cc) { sw(G[0 * 4 + cc], G[2 * 4 + cc]); sw(C[0 * 4 + cc], C[2 * 4 + cc]); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { sw(G[r * 4 + 0], G[r * 4 + 2]); sw(C[r * 4 + 0], C[r * 4 + 2]); }
   }
-  // ---- junction diodes and charges on the true source/drain ----
-  const double vbd = vbs - vds;
-  double ibs, gbs, ibd, gbd, qbs, cbs, qbd, cbd;
-  diode(vbs, P[B4I_Isbs], P[B4I_Nvtms], P[B4I_vjsmFwd], P[B4I_IVjsmFwd], gmin, ibs, gbs);
-  diode(vbd, P[B4I_Isbd], P[B4I_Nvtmd], P[B4I_vjdmFwd], P[B4I_IVjdmFwd], gmin, ibd, gbd);
-  junction(vbs, P[B4I_czbs], P[B4I_czbssw], P[B4I_czbsswg], P[B4I_PhiBS], P[B4I_PhiBSWS], P[B4I_PhiBSWGS], P[B4I_mjs], P[B4I_mjsws], P[B4I_mjswgs], qbs, cbs);
-  junction(vbd, P[B4I_czbd], P[B4I_czbdsw], P[B4I_czbdswg], P[B4I_PhiBD], P[B4I_PhiBSWD], P[B4I_PhiBSWGD], P[B4I_mjd], P[B4I_mjswd], P[B4I_mjswgd], qbd, cbd);
-  // two-terminal element between rows (a: +x, b: -x) depending on v_a - v_b
+  B4Two t;
+  b4_two_terminal(P, vgs, vds, vbs, gmin, t);
   auto two = [&](double* val, double* M, int a, int b, double x, double dx) {
     val[a] += x; val[b] -= x;
     M[a * 4 + a] += dx; M[a * 4 + b] -= dx; M[b * 4 + a] -= dx; M[b * 4 + b] += dx;
   };
-  two(I, G, 3, 2, ibs, gbs); two(I, G, 3, 0, ibd, gbd);
-  two(Qo, C, 3, 2, qbs, cbs); two(Qo, C, 3, 0, qbd, cbd);
-  // ---- overlap charges ----
-  if ((int)P[B4I_capmod] != 0) {
-    double qgd, cgd, qgs, cgs;
-    overlap(vgs - vds, P[B4I_cgdo], P[B4I_cgdlW], P[B4I_ckappad], qgd, cgd);
-    overlap(vgs, P[B4I_cgso], P[B4I_cgslW], P[B4I_ckappas], qgs, cgs);
-    two(Qo, C, 1, 0, qgd, cgd); two(Qo, C, 1, 2, qgs, cgs);
-    const double cgb = P[B4I_cgbo];
-    two(Qo, C, 1, 3, cgb * (vgs - vbs), cgb);
-  }
-  // ---- polarity ----
+  two(I, G, 3, 2, t.ibs, t.gbs); two(I, G, 3, 0, t.ibd, t.gbd);
+  two(Qo, C, 3, 2, t.qbs, t.cbs); two(Qo, C, 3, 0, t.qbd, t.cbd);
+  two(Qo, C, 1, 0, t.qgd, t.cgd); two(Qo, C, 1, 2, t.qgs, t.cgs); two(Qo, C, 1, 3, t.qgb, t.cgb);
 #pragma unroll
   for (int r = 0; r < 4; ++r) { I[r] *= tp; Qo[r] *= tp; }
+}
+
+// Four lanes per instance (a quad, lanes 4q..4q+3 of one wavefront).  Lane `sub` seeds ONE partial
+// (0: Vgs', 1: Vds', 2: Vbs', 3: none), so the dual-number arithmetic per lane shrinks from
+// 1+3 to 1+1 components; the S' column is the negated sum of the other three, formed with two
+// quad shuffles.  Each lane then owns ONE column of the 4x4 G and C stamps and writes it straight
+// into the 40-slot staging record `st` (scaled by the multiplier m); lane 3 also writes I and Q.
+CH_D void b4_device_quad(const B4Col P, double vd, double vg, double vs, double vb, double gmin, int sub, double m, double* st) {
+  const double tp = P[B4I_type];
+  const double vds = tp * (vd - vs), vgs = tp * (vg - vs), vbs = tp * (vb - vs);
+  const bool fwd = vds >= 0.0;
+  typedef DN<1> D1;
+  D1 Vgs = mkd<1>(fwd ? vgs : vgs - vds), Vds = mkd<1>(fwd ? vds : -vds), Vbs = mkd<1>(fwd ? vbs : vbs - vds);
+  Vgs.p[0] = sub == 0 ? 1.0 : 0.0; Vds.p[0] = sub == 1 ? 1.0 : 0.0; Vbs.p[0] = sub == 2 ? 1.0 : 0.0;
+  B4Core<1> c;
+  b4_core<1>(P, Vgs, Vds, Vbs, c);
+  // this lane's column in the mode frame (D'=0, G=1, S'=2, B=3): sub 0 -> G, 1 -> D', 2 -> B, 3 -> S'
+  auto quad_sum = [](double x) { x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); return x; };
+  auto colval = [&](const D1& x) { const double sum = quad_sum(x.p[0]); return sub == 3 ? -sum : x.p[0]; };
+  // mode-frame rows D', G, S', B
+  double gI[4] = {colval(c.iD), 0.0, colval(c.iS), colval(c.iB)};
+  double gQ[4] = {colval(c.qd), colval(c.qg), colval(c.qs), colval(c.qb)};
+  double I4[4] = {c.iD.v, 0.0, c.iS.v, c.iB.v}, Q4[4] = {c.qd.v, c.qg.v, c.qs.v, c.qb.v};
+  int col = sub == 0 ? 1 : (sub == 1 ? 0 : (sub == 2 ? 3 : 2));
+  if (!fwd) {  // mode frame -> true frame: exchange D' and S' (rows, and this lane's column label)
+    auto sw = [](double& x, double& y) { const double t = x; x = y; y = t; };
+    sw(gI[0], gI[2]); sw(gQ[0], gQ[2]); sw(I4[0], I4[2]); sw(Q4[0], Q4[2]);
+    col = col == 0 ? 2 : (col == 2 ? 0 : col);
+  }
+  B4Two t;
+  b4_two_terminal(P, vgs, vds, vbs, gmin, t);
+  // two-terminal element between rows (a,b): this lane's column gets +dx on row a / -dx on row b if
+  // col == a, the opposite if col == b
+  auto two = [&](double* val, double* gcol, int a, int b, double x, double dx) {
+    val[a] += x; val[b] -= x;
+    const double s = col == a ? dx : (col == b ? -dx : 0.0);
+    gcol[a] += s; gcol[b] -= s;
+  };
+  two(I4, gI, 3, 2, t.ibs, t.gbs); two(I4, gI, 3, 0, t.ibd, t.gbd);
+  two(Q4, gQ, 3, 2, t.qbs, t.cbs); two(Q4, gQ, 3, 0, t.qbd, t.cbd);
+  two(Q4, gQ, 1, 0, t.qgd, t.cgd); two(Q4, gQ, 1, 2, t.qgs, t.cgs); two(Q4, gQ, 1, 3, t.qgb, t.cgb);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { st[8 + r * 4 + col] = m * gI[r]; st[24 + r * 4 + col] = m * gQ[r]; }
+  if (sub == 3) {
+    const double mt = m * tp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[r] = mt * I4[r]; st[4 + r] = mt * Q4[r]; }
+  }
 }
 #endif  // __HIPCC__
 

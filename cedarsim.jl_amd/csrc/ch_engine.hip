@@ -169,9 +169,17 @@ struct ch_circuit {
   std::vector<int> mos_cls;                 // [n_mos]
   int n_cls = 0;
   // ---- device buffers ----
-  DevBuf<int> d_comp_class, d_comp_uofs, d_comp_dofs, d_gl_ptr, d_dkind, d_dterm, d_dsrc, d_dcls, d_dhdev, d_obs_unk, d_moscls_inst;
+  DevBuf<int> d_comp_class, d_comp_uofs, d_comp_dofs, d_gl_ptr, d_dkind, d_dterm, d_dsrc, d_dcls, d_dhdev, d_obs_unk, d_moscls_inst, d_slot_tab, d_unk_obs;
+  DevBuf<unsigned long long> d_stamps;
+  std::vector<int> obs_primary;  // per observable: the observable whose device row it shares (itself if primary)
+  DevBuf<int> d_mc_ofs, d_mc_n, d_mc_list, d_dcls_local;
+  int block_threads = 64, lu_variant = 16, max_mc = 0;
+  bool host_reduce = true;      // block outputs land in mapped host memory and the host reduces them
+  BlockOut* h_out = nullptr;    // mapped pinned [n_comp*S]
+  size_t h_out_n = 0;
   DevBuf<ClassMeta> d_classes;
   DevBuf<uint16_t> d_gl_src;
+  DevBuf<double> d_rate;
   DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ;  // (d_srcv unused: source values share d_kv)
   DevBuf<unsigned char> d_dmask, d_active;
   DevBuf<BlockOut> d_out;
@@ -180,16 +188,17 @@ struct ch_circuit {
   double* h_stage = nullptr;    // pinned staging for kv/srcv uploads
   size_t h_stage_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0, lds_doubles_fixed = 0, lds_extra_bytes = 0;
   NewtonArgs base;              // structure pointers filled once
   // stats
-  double device_ms = 0; long n_launch = 0;
+  double device_ms = 0; long n_launch = 0, n_timed = 0;  // device_ms sums the sampled launches only
 
   std::string& err() { return ctx->err; }
   void set_err(const std::string& s) { ctx->err = s; }
 
   ~ch_circuit() {
     if (h_sum) (void)hipHostFree(h_sum);
+    if (h_out) (void)hipHostFree(h_out);
     if (h_stage) (void)hipHostFree(h_stage);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -198,26 +207,47 @@ struct ch_circuit {
   // ------------------------------------------------------------------------------------------
   int upload_structure() {
     hipStream_t st = ctx->stream;
-    std::vector<ClassMeta> cms; std::vector<int> ptr; std::vector<uint16_t> srcs;
-    for (const CompClass& c : A.classes) {
-      ClassMeta m; m.nc = c.nc; m.ndev = c.ndev; m.nonlinear = c.nonlinear ? 1 : 0; m.pad = 0;
+    std::vector<ClassMeta> cms; std::vector<int> ptr, slot_tab; std::vector<uint16_t> srcs;
+    int max_slots = 0;
+    for (size_t ci = 0; ci < A.classes.size(); ++ci) {
+      const CompClass& c = A.classes[ci];
+      ClassMeta m; std::memset(&m, 0, sizeof(m));
+      m.nc = c.nc; m.ndev = c.ndev; m.nonlinear = c.nonlinear ? 1 : 0;
       m.mat_ptr_ofs = (int)ptr.size(); ptr.insert(ptr.end(), c.mat_ptr.begin(), c.mat_ptr.end());
       m.vec_ptr_ofs = (int)ptr.size(); ptr.insert(ptr.end(), c.vec_ptr.begin(), c.vec_ptr.end());
       m.mat_src_ofs = (int)srcs.size(); srcs.insert(srcs.end(), c.mat_src.begin(), c.mat_src.end());
       m.vec_src_ofs = (int)srcs.size(); srcs.insert(srcs.end(), c.vec_src.begin(), c.vec_src.end());
+      m.n_mat_src = (int)c.mat_src.size(); m.n_vec_src = (int)c.vec_src.size();
+      // lane slots of the evaluation phase
+      m.slot_ofs = (int)slot_tab.size();
+      int rep = -1;
+      for (int k = 0; k < A.n_comp; ++k) if (A.comp_class[k] == (int)ci) { rep = k; break; }
+      // one lane per device instance; MOSFETs first so that the expensive lanes share wavefronts
+      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind == K_MOS) slot_tab.push_back(d << 2);
+      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind != K_MOS) slot_tab.push_back(d << 2);
+      m.nslots = (int)slot_tab.size() - m.slot_ofs;
+      max_slots = std::max(max_slots, m.nslots);
       cms.push_back(m);
     }
+    block_threads = std::min(256, std::max(64, ((max_slots + 63) / 64) * 64));
+    lu_variant = A.max_nc <= 8 ? 8 : (A.max_nc <= 12 ? 12 : (A.max_nc <= 16 ? 16 : (A.max_nc <= 32 ? 32 : 0)));
     std::vector<int> dkind, dterm, dsrc, dhdev;
     for (const EDev& e : A.edev) { dkind.push_back(e.kind); for (int k = 0; k < 4; ++k) dterm.push_back(e.term[k]); dsrc.push_back(e.src < 0 ? 0 : e.src); dhdev.push_back(e.hdev); }
     std::vector<unsigned char> dm(A.n_unk, 0);
     for (int u = 0; u < A.n_unk; ++u) dm[u] = (A.diff_mask[u] ? 1 : 0) | (A.unk_mna[u] >= n_nodes ? 2 : 0);
-    std::vector<int> obs_unk;
+    std::vector<int> obs_unk, unk_obs(A.n_unk, -1);
+    obs_primary.clear();
     for (size_t o = 0; o < obs_kind.size(); ++o) {
       int u = -1;
       if (obs_kind[o] == 0) u = A.node_unknown[obs_index[o]];
       else { int b = dev[obs_index[o]].branch; u = b >= 0 ? A.branch_unknown[b] : -1; }
       obs_unk.push_back(u);
+      int prim = (int)o;
+      if (u >= 0) { if (unk_obs[u] < 0) unk_obs[u] = (int)o; else prim = unk_obs[u]; }
+      obs_primary.push_back(prim);
     }
+    HIPCHK(d_unk_obs.upload(unk_obs, st)); HIPCHK(d_slot_tab.upload(slot_tab, st));
+    { std::vector<unsigned long long> z(8, 0ull); HIPCHK(d_stamps.upload(z, st)); }
     HIPCHK(d_classes.upload(cms, st)); HIPCHK(d_gl_ptr.upload(ptr, st)); HIPCHK(d_gl_src.upload(srcs, st));
     HIPCHK(d_comp_class.upload(A.comp_class, st)); HIPCHK(d_comp_uofs.upload(A.comp_uofs, st)); HIPCHK(d_comp_dofs.upload(A.comp_dofs, st));
     HIPCHK(d_dkind.upload(dkind, st)); HIPCHK(d_dterm.upload(dterm, st)); HIPCHK(d_dsrc.upload(dsrc, st)); HIPCHK(d_dhdev.upload(dhdev, st));
@@ -225,11 +255,13 @@ struct ch_circuit {
     HIPCHK(d_sum.alloc(1));
     HIPCHK(hipHostMalloc((void**)&h_sum, sizeof(Summary), hipHostMallocMapped));
     HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
-    size_t ld = 0;
-    for (const CompClass& c : A.classes) ld = std::max(ld, (size_t)c.ndev * 40 + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 8 * (size_t)c.nc);
-    lds_bytes = ld * sizeof(double);
-    if (lds_bytes > 150 * 1024) { set_err("a Jacobian block needs more LDS than one CU has; the sparse path for large coupled blocks is not built yet"); return CH_ERR_UNSUPPORTED; }
-    if (lds_bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    lds_doubles_fixed = 0; lds_extra_bytes = 0;
+    for (size_t ci = 0; ci < A.classes.size(); ++ci) {
+      const CompClass& c = A.classes[ci];
+      lds_doubles_fixed = std::max(lds_doubles_fixed, (size_t)c.ndev * 40 + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 8 * (size_t)c.nc);
+      const size_t ints = (size_t)c.nc * c.nc + 1 + c.nc + 1 + cms[ci].nslots + 64;  // + scratch for the block's MOS class list
+      lds_extra_bytes = std::max(lds_extra_bytes, ints * 4 + (c.mat_src.size() + c.vec_src.size()) * 2 + 16);
+    }
     return CH_OK;
   }
 
@@ -309,13 +341,34 @@ struct ch_circuit {
         ip[CH_MOS_W] *= scale; ip[CH_MOS_L] *= scale;
         int rc = b4_pack(card.data(), ip, tc, col.data());
         if (rc != CH_OK) { set_err(rc == CH_ERR_UNSUPPORTED ? "BSIM4 card selects a sub-model the engine does not implement (rdsmod/rgatemod/rbodymod/igcmod/igbmod/trnqsmod/geomod != 0, diomod != 1, mobmod > 2, capmod not 0/2)" : "invalid MOS geometry or model card"); return rc; }
-        for (int k = 0; k < B4I_COUNT; ++k) table[(size_t)k * cols + (size_t)c * Smos + s] = col[k];
+        for (int k = 0; k < B4I_COUNT; ++k) table[((size_t)c * Smos + s) * B4I_COUNT + k] = col[k];
       }
     }
     HIPCHK(d_mosp.upload(table, st));
     std::vector<int> dcls;
     for (const EDev& e : A.edev) dcls.push_back(e.mos >= 0 ? mos_cls[e.mos] : 0);
     HIPCHK(d_dcls.upload(dcls, st));
+    {  // per block: the distinct MOS classes its devices use, and each device's index into that list
+      std::vector<int> mc_ofs(A.n_comp), mc_n(A.n_comp), mc_list, dloc(A.edev.size(), 0);
+      max_mc = 0;
+      for (int k = 0; k < A.n_comp; ++k) {
+        mc_ofs[k] = (int)mc_list.size();
+        std::vector<int> seen;
+        for (int d = 0; d < A.comp_ndev[k]; ++d) {
+          const EDev& e = A.edev[A.comp_dofs[k] + d];
+          if (e.mos < 0) continue;
+          const int cl = mos_cls[e.mos];
+          int j = (int)(std::find(seen.begin(), seen.end(), cl) - seen.begin());
+          if (j == (int)seen.size()) seen.push_back(cl);
+          dloc[A.comp_dofs[k] + d] = j;
+        }
+        mc_n[k] = (int)seen.size();
+        mc_list.insert(mc_list.end(), seen.begin(), seen.end());
+        max_mc = std::max(max_mc, mc_n[k]);
+      }
+      if (max_mc > 64) { set_err("a Jacobian block uses more than 64 distinct MOSFET classes"); return CH_ERR_UNSUPPORTED; }
+      HIPCHK(d_mc_ofs.upload(mc_ofs, st)); HIPCHK(d_mc_n.upload(mc_n, st)); HIPCHK(d_mc_list.upload(mc_list, st)); HIPCHK(d_dcls_local.upload(dloc, st));
+    }
     HIPCHK(d_moscls_inst.upload(mos_cls, st));
     // state ring and outputs
     const size_t slot_elems = (size_t)S * A.n_unk;
@@ -323,6 +376,13 @@ struct ch_circuit {
     HIPCHK(hipMemsetAsync(d_X.p, 0, slot_elems * NSLOT * sizeof(double), st));
     HIPCHK(hipMemsetAsync(d_Q.p, 0, slot_elems * NSLOT * sizeof(double), st));
     HIPCHK(d_out.alloc((size_t)A.n_comp * S));
+    { std::vector<double> ones((size_t)A.n_comp * S, 1.0); HIPCHK(d_rate.upload(ones, st)); }
+    host_reduce = (size_t)A.n_comp * S <= 4096 && std::getenv("CEDARHIP_DEVICE_REDUCE") == nullptr;
+    if (host_reduce && h_out_n < (size_t)A.n_comp * S) {
+      if (h_out) (void)hipHostFree(h_out);
+      HIPCHK(hipHostMalloc((void**)&h_out, (size_t)A.n_comp * S * sizeof(BlockOut), hipHostMallocMapped));
+      h_out_n = (size_t)A.n_comp * S;
+    }
     HIPCHK(d_active.alloc((size_t)A.n_comp * S));
     const size_t need = (size_t)Ssrc * (A.known.size() + std::max(1, nsrc));
     HIPCHK(d_kv.alloc(need));  // [kv | srcv] contiguous: one upload per step
@@ -336,7 +396,23 @@ struct ch_circuit {
     a.active = nullptr; a.gmin_s = d_gmin.p;
     a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = std::max(1, nsrc);
     a.n_unk = A.n_unk; a.n_mos_cls = n_cls;
-    a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = d_out.p;
+    a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = host_reduce ? h_out : d_out.p;
+    a.slot_tab = d_slot_tab.p; a.unk_obs = d_unk_obs.p; a.n_obs = (int)obs_kind.size();
+    a.dcls_local = d_dcls_local.p; a.comp_mc_ofs = d_mc_ofs.p; a.comp_mc_n = d_mc_n.p; a.mc_list = d_mc_list.p; a.max_mc = max_mc;
+    a.summary = h_sum; a.rate = d_rate.p;
+#ifdef CH_STAMPS
+    a.stamps = d_stamps.p;
+#endif
+    lds_bytes = (lds_doubles_fixed + A.known.size() + std::max(1, nsrc) + (size_t)max_mc * B4I_COUNT) * sizeof(double) + lds_extra_bytes;
+    lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
+    if (lds_bytes > 156 * 1024) { set_err("a Jacobian block needs more LDS than one CU has; the sparse path for large coupled blocks is not built yet"); return CH_ERR_UNSUPPORTED; }
+    if (lds_bytes > 48 * 1024) {
+      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
     HIPCHK(hipStreamSynchronize(st));
     dirty = false;
     return CH_OK;
@@ -351,30 +427,71 @@ struct ch_circuit {
       for (int k = 0; k < nk; ++k) { double v = 0; for (auto& tm : A.known[k].terms) v += tm.second * sv[(size_t)s * std::max(1, nsrc) + tm.first]; kv[(size_t)s * nk + k] = v; }
     }
   }
-  int upload_sources(double t, int mode) {
-    std::vector<double> sv, kv;
+  // Source / known-node values for the next launch: passed inside the kernel arguments when they are
+  // sample-independent and few (no H2D copy at all), otherwise one small upload.
+  std::vector<double> sv_buf, kv_buf;
+  int set_sources(NewtonArgs& a, double t, int mode) {
+    std::vector<double>& sv = sv_buf; std::vector<double>& kv = kv_buf;
     eval_sources(t, mode, sv, kv);
+    if (Ssrc == 1 && kv.size() + sv.size() <= (size_t)KV_INLINE) {
+      a.inline_vals = 1;
+      for (size_t i = 0; i < kv.size(); ++i) a.vals_inline[i] = kv[i];
+      for (size_t i = 0; i < sv.size(); ++i) a.vals_inline[kv.size() + i] = sv[i];
+      return CH_OK;
+    }
+    a.inline_vals = 0;
+    // the pinned staging buffer is reused every step: the stream sync at the end of each step protects it
     std::memcpy(h_stage, kv.data(), kv.size() * sizeof(double));
     std::memcpy(h_stage + kv.size(), sv.data(), sv.size() * sizeof(double));
     HIPCHK(hipMemcpyAsync(d_kv.p, h_stage, (kv.size() + sv.size()) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    // the pinned staging buffer is reused next step: the stream sync at the end of the step protects it
     return CH_OK;
   }
 
   // launch the fused Newton kernel + reduction and wait for the summary
-  int run_newton(const NewtonArgs& a, const unsigned char* active, Summary& out) {
+  // host_active: host copy of the per-block active mask given to the kernel (DC restart passes, ch_eval), or null
+  int run_newton(const NewtonArgs& a, const unsigned char* host_active, Summary& out) {
     hipStream_t st = ctx->stream;
     const int nblk = A.n_comp * S;
-    HIPCHK(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(newton_block_kernel, dim3(nblk), dim3(64), lds_bytes, st, a);
-    HIPCHK(hipEventRecord(ev1, st));
-    // the 64-byte summary is written straight into mapped pinned host memory (no D2H copy op)
-    hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 0, st, (const BlockOut*)d_out.p, A.n_comp, S, a.ck, a.ckm1, a.ckp1, active, h_sum);
-    HIPCHK(hipStreamSynchronize(st));
+    // kernel duration is sampled with HIP events on 1 launch in 4 (the events cost host time on every step)
+    const bool timed = (n_launch & 3) == 0;
+    if (timed) HIPCHK(hipEventRecord(ev0, st));
+    if (lu_variant == 8) hipLaunchKernelGGL(newton_block_kernel<8>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+    else if (lu_variant == 12) hipLaunchKernelGGL(newton_block_kernel<12>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+    else if (lu_variant == 16) hipLaunchKernelGGL(newton_block_kernel<16>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+    else if (lu_variant == 32) hipLaunchKernelGGL(newton_block_kernel<32>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+    else hipLaunchKernelGGL(newton_block_kernel<0>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+    if (timed) HIPCHK(hipEventRecord(ev1, st));
+    if (!host_reduce) hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 9 * 256 * sizeof(double), st, a);
+    // the host thread has nothing else to do: poll for completion instead of sleeping on an interrupt
+    {
+      hipError_t q = hipErrorNotReady;
+      for (int spin = 0; spin < 200000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(st);
+      if (q == hipErrorNotReady) q = hipStreamSynchronize(st);
+      if (q != hipSuccess) { set_err(std::string("newton kernel: ") + hipGetErrorString(q)); return CH_ERR_DEVICE; }
+    }
     HIPCHK(hipGetLastError());
-    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-    device_ms += ms; n_launch += 1;
-    out = *h_sum;
+    if (timed) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); device_ms += ms; n_timed += 1; }
+    n_launch += 1;
+    if (!host_reduce) out = *h_sum;
+    else {
+      // host-side reduction of the per-block records (same arithmetic as reduce_all_blocks)
+      Summary r; std::memset(&r, 0, sizeof(r));
+      for (int s = 0; s < S; ++s) {
+        double e2[3] = {0, 0, 0}; long nd = 0; int smx = 0;
+        for (int k = 0; k < A.n_comp; ++k) {
+          const size_t b = (size_t)k * S + s;
+          if (host_active && !host_active[b]) continue;
+          const BlockOut& o = h_out[b];
+          e2[0] += o.e2k; e2[1] += o.e2km1; e2[2] += o.e2kp1; nd += o.ndiff;
+          if (o.status != 0) ++r.n_fail;
+          if (o.status == 2) ++r.n_singular;
+          smx = std::max(smx, o.iters); r.sum_block_iters += o.iters; r.fnorm = std::max(r.fnorm, o.fnorm);
+        }
+        r.sum_iters += smx; r.max_iters = std::max(r.max_iters, smx);
+        if (nd > 0) { r.errk = std::max(r.errk, a.ck * std::sqrt(e2[0] / nd)); r.errkm1 = std::max(r.errkm1, a.ckm1 * std::sqrt(e2[1] / nd)); r.errkp1 = std::max(r.errkp1, a.ckp1 * std::sqrt(e2[2] / nd)); }
+      }
+      out = r;
+    }
     return CH_OK;
   }
 
@@ -404,8 +521,7 @@ struct ch_circuit {
   int dc_solve(const ch_dc_opts& o, int slot, std::vector<int>* status_out, ch_stats* stt) {
     const int mode = o.tran_mode ? 2 : 0;
     const int nblk = A.n_comp * S;
-    int rc = upload_sources(0.0, mode);
-    if (rc != CH_OK) return rc;
+    int rc = CH_OK;
     std::vector<unsigned char> active(nblk, 1);
     std::vector<double> xs((size_t)S * A.n_unk), xm(A.n_mna);
     std::vector<BlockOut> bo(nblk);
@@ -413,6 +529,8 @@ struct ch_circuit {
     a.mode = MODE_DC; a.maxit = std::max(1, o.maxiters); a.dc_abstol = o.abstol; a.dv_max = o.dv_max; a.gshunt = 0.0;
     a.abstol = 1e-6; a.reltol = 1e-3; a.newton_tol = 0.1;
     a.hist_slot[0] = slot; a.cand_slot = slot; a.active = d_active.p;
+    rc = set_sources(a, 0.0, mode);
+    if (rc != CH_OK) return rc;
     std::vector<Rng> rngs; for (int s = 0; s < S; ++s) rngs.emplace_back(o.seed + (uint64_t)s);
     auto block_of_unknown = [&](int u) { int c = (int)(std::upper_bound(A.comp_uofs.begin(), A.comp_uofs.end(), u) - A.comp_uofs.begin()) - 1; return c; };
     int n_active = nblk;
@@ -435,17 +553,17 @@ struct ch_circuit {
       HIPCHK(hipMemcpy(d_active.p, active.data(), nblk, hipMemcpyHostToDevice));
       Summary sm;
       if (!homotopy) {
-        rc = run_newton(a, d_active.p, sm);
+        rc = run_newton(a, active.data(), sm);
         if (rc != CH_OK) return rc;
       } else {
         // gmin stepping: a shunt conductance on every node, relaxed decade by decade, then removed
-        for (double g = 1e-2; g >= 1e-13 * 0.99; g *= 0.1) { a.gshunt = g; rc = run_newton(a, d_active.p, sm); if (rc != CH_OK) return rc; }
+        for (double g = 1e-2; g >= 1e-13 * 0.99; g *= 0.1) { a.gshunt = g; rc = run_newton(a, active.data(), sm); if (rc != CH_OK) return rc; }
         a.gshunt = 0.0;
-        rc = run_newton(a, d_active.p, sm);
+        rc = run_newton(a, active.data(), sm);
         if (rc != CH_OK) return rc;
       }
       if (stt) { stt->n_block_iters += sm.sum_block_iters; stt->nnonliniter += sm.sum_iters; stt->nf += sm.sum_iters; stt->njacs += sm.sum_iters; stt->nfactors += sm.sum_iters; stt->nsolve += sm.sum_iters; }
-      HIPCHK(hipMemcpy(bo.data(), d_out.p, nblk * sizeof(BlockOut), hipMemcpyDeviceToHost));
+      if (host_reduce) std::memcpy(bo.data(), h_out, nblk * sizeof(BlockOut)); else HIPCHK(hipMemcpy(bo.data(), d_out.p, nblk * sizeof(BlockOut), hipMemcpyDeviceToHost));
       n_active = 0;
       for (int b = 0; b < nblk; ++b) if (active[b]) { if (bo[b].status == 0) active[b] = 0; else ++n_active; }
       if (n_active > 0 && stt) { stt->nrestarts++; stt->nnonlinconvfail++; }
@@ -460,7 +578,7 @@ struct ch_circuit {
     auto tstart = hclock::now();
     std::memset(&R.stats, 0, sizeof(R.stats));
     R.S = S; R.n_obs = (int)obs_kind.size();
-    device_ms = 0; n_launch = 0;
+    device_ms = 0; n_launch = 0; n_timed = 0;
     int rc = finalize_params();
     if (rc != CH_OK) return rc;
     hipStream_t st = ctx->stream;
@@ -486,8 +604,8 @@ struct ch_circuit {
     R.stats.dc_seconds = std::chrono::duration<double>(hclock::now() - tstart).count();
     // charges at t0 in the problem's own mode
     {
-      rc = upload_sources(t0, 1); if (rc != CH_OK) return rc;
       NewtonArgs a = base; a.mode = MODE_EVAL; a.maxit = 1; a.hist_slot[0] = order[0]; a.cand_slot = order[0]; a.abstol = o.abstol; a.reltol = o.reltol;
+      rc = set_sources(a, t0, 1); if (rc != CH_OK) return rc;
       Summary sm; rc = run_newton(a, nullptr, sm); if (rc != CH_OK) return rc;
       R.stats.nf += S;
     }
@@ -503,12 +621,18 @@ struct ch_circuit {
 
     // saved observables live on the device until the end
     std::vector<double*> chunks; const int CH = 512; long nsaved = 0;
+    auto row_ptr = [&](long row, double** out) -> int {  // device address of saved-row `row`, growing the buffer by chunks
+      while ((size_t)(row / CH) >= chunks.size()) { double* p = nullptr; HIPCHK(hipMalloc((void**)&p, std::max<size_t>(1, (size_t)CH * n_obs * S) * sizeof(double))); chunks.push_back(p); }
+      *out = chunks[row / CH] + (size_t)(row % CH) * n_obs * S;
+      return CH_OK;
+    };
     auto save = [&](double ts, const int* slots, const double* w, int nw) -> int {
-      if ((nsaved % CH) == 0) { double* p = nullptr; HIPCHK(hipMalloc((void**)&p, std::max<size_t>(1, (size_t)CH * n_obs * S) * sizeof(double))); chunks.push_back(p); }
+      double* dst = nullptr;
+      int r0 = row_ptr(nsaved, &dst); if (r0 != CH_OK) return r0;
       if (n_obs > 0) {
         ObsArgs oa; oa.X = d_X.p; oa.slot_stride = (long)S * A.n_unk; oa.nw = nw; oa.n_unk = A.n_unk; oa.S = S; oa.n_obs = n_obs; oa.obs_unk = d_obs_unk.p;
         for (int j = 0; j < nw; ++j) { oa.slots[j] = slots[j]; oa.w[j] = w[j]; }
-        oa.dst = chunks.back() + (size_t)(nsaved % CH) * n_obs * S;
+        oa.dst = dst;
         const int n = n_obs * S;
         hipLaunchKernelGGL(save_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, oa);
       }
@@ -529,6 +653,7 @@ struct ch_circuit {
     double tau[9];
     NewtonArgs a = base;
     a.mode = MODE_TRAN; a.maxit = nmaxit; a.abstol = o.abstol; a.reltol = o.reltol; a.newton_tol = 0.1;
+    bool reset_rate = true;  // convergence rates unknown at the start and after every restart
 
     for (int step = 0; step < max_steps && t < t1;) {
       while (ibp < bps.size() && bps[ibp] <= t * (1 + 1e-15) + 1e-300) ++ibp;
@@ -551,12 +676,15 @@ struct ch_circuit {
       for (int j = 0; j < 7; ++j) a.hist_slot[j] = order[std::min(j, nh - 1)];
       a.cand_slot = order[NSLOT - 1];
       // landing on a break point uses the sources' left limit there; the jump (if any) is crossed by the restart step
-      rc = upload_sources(hit_bp ? std::nextafter(tn, -INFINITY) : tn, 1); if (rc != CH_OK) { status = rc; break; }
+      rc = set_sources(a, hit_bp ? std::nextafter(tn, -INFINITY) : tn, 1); if (rc != CH_OK) { status = rc; break; }
+      a.reset_rate = reset_rate ? 1 : 0;
+      a.obs_row = nullptr;
+      if (o.n_saveat == 0 && n_obs > 0) { rc = row_ptr(nsaved, &a.obs_row); if (rc != CH_OK) { status = rc; break; } }  // candidate row, kept on accept
       Summary sm;
       rc = run_newton(a, nullptr, sm); if (rc != CH_OK) { status = rc; break; }
       R.stats.n_block_iters += sm.sum_block_iters; R.stats.nnonliniter += sm.sum_iters; R.stats.nf += sm.sum_iters; R.stats.njacs += sm.sum_iters; R.stats.nfactors += sm.sum_iters; R.stats.nsolve += sm.sum_iters;
       if (sm.n_fail > 0) {
-        R.stats.nnonlinconvfail++;
+        R.stats.nnonlinconvfail++; reset_rate = true;
         h = hh * 0.25; k = 1; steps_at_order = 0;
         if (nhist > 2) nhist = 2;
         continue;
@@ -571,7 +699,7 @@ struct ch_circuit {
         continue;
       }
       // ---- accept: candidate slot becomes the newest history point ----
-      R.stats.naccept++; ++step;
+      R.stats.naccept++; ++step; reset_rate = false;
       { int cand = order[NSLOT - 1]; for (int j = NSLOT - 1; j > 0; --j) { order[j] = order[j - 1]; htime[j] = htime[j - 1]; } order[0] = cand; htime[0] = tn; nhist = std::min(nhist + 1, kmax + 2); }
       if (o.n_saveat > 0) {
         while (isave < o.n_saveat && o.saveat[isave] <= tn * (1 + 1e-15)) {
@@ -582,7 +710,8 @@ struct ch_circuit {
           rc = save(ts, order, ww + 1, m); if (rc) break;
           ++isave;
         }
-      } else { const double one = 1.0; rc = save(tn, order, &one, 1); }
+      } else if (n_obs > 0) { R.times.push_back(tn); ++nsaved; }  // the kernel's epilogue already wrote this row
+      else { const double one = 1.0; rc = save(tn, order, &one, 1); }
       if (rc != CH_OK) { status = rc; break; }
       // ---- order / step selection ----
       const double fac_k = std::pow(2.0 * errk + 1e-4, -1.0 / (kk + 1));  // puts the error at half the tolerance
@@ -598,7 +727,7 @@ struct ch_circuit {
       h = std::min(dtmax, hh * std::min(kk == 1 ? 10.0 : 2.0, std::max(0.5, best)));
       t = tn;
       if (hit_bp && t < t1) {
-        nhist = 1; k = 1; steps_at_order = 0;
+        nhist = 1; k = 1; steps_at_order = 0; reset_rate = true;
         double nb = t1;
         for (size_t b = ibp; b < bps.size(); ++b) if (bps[b] > t * (1 + 1e-15)) { nb = bps[b]; break; }
         h = std::max(dtmin * 10, std::min(h, (nb - t) / 50.0) * kFirstFrac);
@@ -619,6 +748,9 @@ struct ch_circuit {
           std::memcpy(&R.values[((size_t)ob * nt + cidx * CH + r) * S], &buf[(r * n_obs + ob) * S], S * sizeof(double));
       }
       free_chunks();
+      // several observables fed by one unknown (merged nodes): the kernel writes the primary one only
+      for (int ob = 0; ob < n_obs; ++ob) if (obs_primary[ob] != ob)
+        std::memcpy(&R.values[(size_t)ob * nt * S], &R.values[(size_t)obs_primary[ob] * nt * S], nt * S * sizeof(double));
       // observables that are known nodes / ground are evaluated on the host
       const int nk = (int)A.known.size();
       std::vector<double> sv, kv;
@@ -634,9 +766,13 @@ struct ch_circuit {
     }
     R.final_state.assign((size_t)S * A.n_mna, 0.0);
     download_mna(order[0], t, 1, R.final_state.data());
+#ifdef CH_STAMPS
+    { unsigned long long hs[8]; (void)hipMemcpy(hs, d_stamps.p, sizeof(hs), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "[stamps] cycles summed over blocks: prologue %llu eval %llu gather %llu solve %llu epilogue %llu arrival %llu pre-LU %llu LU %llu ; launches %ld blocks %d\n", hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7], n_launch, A.n_comp * S); }
+#endif
     R.status = status;
     R.stats.wall_seconds = std::chrono::duration<double>(hclock::now() - tstart).count();
-    R.stats.device_seconds = device_ms * 1e-3;
+    R.stats.device_seconds = n_timed > 0 ? device_ms * 1e-3 * (double)n_launch / (double)n_timed : 0.0;  // scaled from the sampled launches
     R.stats.n_kernel_launches = n_launch;
     if (status != CH_OK && err().empty()) set_err(status == CH_ERR_DTMIN ? "step size underflow (DtLessThanMin)" : "transient did not reach t1");
     return status;
@@ -761,7 +897,7 @@ int ch_dc(ch_circuit* c, const ch_dc_opts* o, double* x_out, int32_t* status_out
   (void)hipSetDevice(c->ctx->device);
   auto t0 = hclock::now();
   ch_stats st; std::memset(&st, 0, sizeof(st));
-  c->device_ms = 0; c->n_launch = 0;
+  c->device_ms = 0; c->n_launch = 0; c->n_timed = 0;
   int rc = c->finalize_params();
   if (rc != CH_OK) return rc;
   std::vector<int> status;
@@ -769,7 +905,7 @@ int ch_dc(ch_circuit* c, const ch_dc_opts* o, double* x_out, int32_t* status_out
   if (x_out) { int r2 = c->download_mna(0, 0.0, o->tran_mode ? 2 : 0, x_out); if (r2 != CH_OK) return r2; }
   if (status_out) for (int s = 0; s < c->S; ++s) status_out[s] = status.empty() ? rc : status[s];
   st.wall_seconds = st.dc_seconds = std::chrono::duration<double>(hclock::now() - t0).count();
-  st.device_seconds = c->device_ms * 1e-3; st.n_kernel_launches = c->n_launch;
+  st.device_seconds = c->n_timed > 0 ? c->device_ms * 1e-3 * (double)c->n_launch / (double)c->n_timed : 0.0; st.n_kernel_launches = c->n_launch;
   if (stats) *stats = st;
   return rc;
 }
@@ -808,13 +944,13 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
   for (int k = 0; k < A.n_comp; ++k) act[(size_t)k * S + sample] = 1;
   if (hipMemcpy(c->d_active.p, act.data(), nblk, hipMemcpyHostToDevice) != hipSuccess) return CH_ERR_DEVICE;
   if (c->d_dumpA.alloc((size_t)nblk * ds * ds) != hipSuccess || c->d_dumpF.alloc((size_t)nblk * ds) != hipSuccess || c->d_dumpQ.alloc((size_t)nblk * ds) != hipSuccess) return CH_ERR_DEVICE;
-  rc = c->upload_sources(t, mode == 0 ? 0 : 1);
-  if (rc != CH_OK) return rc;
   NewtonArgs a = c->base;
+  rc = c->set_sources(a, t, mode == 0 ? 0 : 1);
+  if (rc != CH_OK) return rc;
   a.mode = MODE_EVAL; a.maxit = 1; a.alpha[0] = alpha0; a.hist_slot[0] = 0; a.cand_slot = 1; a.active = c->d_active.p; a.abstol = 1e-6; a.reltol = 1e-3;
   a.dumpA = c->d_dumpA.p; a.dumpF = c->d_dumpF.p; a.dumpQ = c->d_dumpQ.p; a.dump_stride = ds;
   Summary sm;
-  rc = c->run_newton(a, c->d_active.p, sm);
+  rc = c->run_newton(a, act.data(), sm);
   if (rc != CH_OK) return rc;
   std::vector<double> hA((size_t)nblk * ds * ds), hF((size_t)nblk * ds), hQ((size_t)nblk * ds);
   (void)hipMemcpy(hA.data(), c->d_dumpA.p, hA.size() * sizeof(double), hipMemcpyDeviceToHost);
@@ -839,7 +975,7 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
   return CH_OK;
 }
 
-int ch_mos_eval(ch_circuit* c, int32_t sample, const double* v, double* out) {
+static int mos_eval_impl(ch_circuit* c, int32_t sample, const double* v, double* out, bool quad) {
   if (!c || !v || !out || sample < 0 || sample >= c->S) return CH_ERR_INVALID;
   c->ctx->err.clear();
   (void)hipSetDevice(c->ctx->device);
@@ -852,13 +988,17 @@ int ch_mos_eval(ch_circuit* c, int32_t sample, const double* v, double* out) {
   (void)hipMemcpy(dv, v, (size_t)nm * 4 * sizeof(double), hipMemcpyHostToDevice);
   std::vector<double> hg(c->Sgmin);
   (void)hipMemcpy(hg.data(), c->d_gmin.p, hg.size() * sizeof(double), hipMemcpyDeviceToHost);
-  hipLaunchKernelGGL(mos_eval_kernel, dim3((nm + 63) / 64), dim3(64), 0, c->ctx->stream, (const double*)c->d_mosp.p, c->base.mos_cols, (const int*)c->d_moscls_inst.p, c->Smos, (int)sample, nm, (const double*)dv, hg[c->Sgmin > 1 ? sample : 0], dout);
+  const double gm = hg[c->Sgmin > 1 ? sample : 0];
+  if (quad) hipLaunchKernelGGL(mos_eval_quad_kernel, dim3((nm * 4 + 63) / 64), dim3(64), 0, c->ctx->stream, (const double*)c->d_mosp.p, c->base.mos_cols, (const int*)c->d_moscls_inst.p, c->Smos, (int)sample, nm, (const double*)dv, gm, dout);
+  else hipLaunchKernelGGL(mos_eval_kernel, dim3((nm + 63) / 64), dim3(64), 0, c->ctx->stream, (const double*)c->d_mosp.p, c->base.mos_cols, (const int*)c->d_moscls_inst.p, c->Smos, (int)sample, nm, (const double*)dv, gm, dout);
   hipError_t e = hipStreamSynchronize(c->ctx->stream);
   if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)nm * 40 * sizeof(double), hipMemcpyDeviceToHost);
   (void)hipFree(dv); (void)hipFree(dout);
   if (e != hipSuccess) { c->set_err(hipGetErrorString(e)); return CH_ERR_DEVICE; }
   return CH_OK;
 }
+int ch_mos_eval(ch_circuit* c, int32_t sample, const double* v, double* out) { return mos_eval_impl(c, sample, v, out, false); }
+int ch_mos_eval_quad(ch_circuit* c, int32_t sample, const double* v, double* out) { return mos_eval_impl(c, sample, v, out, true); }
 
 static const char* const k_b4_names[] = {
 #define P(n, d) #n,

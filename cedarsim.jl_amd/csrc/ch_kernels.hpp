@@ -24,8 +24,9 @@
 namespace chip {
 
 struct ClassMeta {
-  int nc, ndev, nonlinear, pad;
+  int nc, ndev, nonlinear, nslots;   // nslots: lane slots of the evaluation phase (4 per MOSFET, 1 otherwise)
   int mat_ptr_ofs, mat_src_ofs, vec_ptr_ofs, vec_src_ofs;  // offsets into the pooled gather arrays
+  int n_mat_src, n_vec_src, slot_ofs, pad;                  // list lengths; offset into the slot table
 };
 
 struct BlockOut {
@@ -46,31 +47,47 @@ struct Summary {
 };
 
 enum { MODE_DC = 0, MODE_TRAN = 1, MODE_EVAL = 2 };
+constexpr int KV_INLINE = 24;
 
 struct NewtonArgs {
   // ---- circuit structure ----
   const int* comp_class; const int* comp_uofs; const int* comp_dofs;
-  const ClassMeta* classes; const int* gl_ptr; const uint16_t* gl_src;
+  const ClassMeta* classes; const int* gl_ptr; const uint16_t* gl_src; const int* slot_tab;
   const int* dkind; const int* dterm; const int* dsrc; const int* dcls; const int* dhdev;
+  const int* dcls_local;                     // per device: index into its block's MOS class list
+  const int* comp_mc_ofs; const int* comp_mc_n; const int* mc_list;  // per block: distinct MOS classes
   const double* dpar; const double* dmult;   // [n_hdev * Spar]
-  const double* mosp; long mos_cols;         // packed BSIM4 table [B4I_COUNT][mos_cols]
+  const double* mosp; long mos_cols;         // packed BSIM4 table [mos_cols][B4I_COUNT]
   const double* kv; const double* srcv;      // known-node values [Ssrc][nk], source values [Ssrc][nsrc]
   const unsigned char* dmask;                // per unknown: bit0 differential, bit1 branch current
   const unsigned char* active;               // per block (DC restarts) or null
   const double* gmin_s;                      // [Sgmin]
-  int n_comp, S, Spar, Ssrc, Smos, Sgmin, nk, nsrc, n_unk, n_mos_cls;
+  const int* unk_obs;                        // per unknown: observable row it feeds, or -1
+  int n_comp, S, Spar, Ssrc, Smos, Sgmin, nk, nsrc, n_unk, n_mos_cls, n_obs, max_mc;
   // ---- state ring: X, Qh are [n_slots][S][n_unk] ----
   double* X; double* Qh; long slot_stride;
   int hist_slot[8]; int cand_slot;
   // ---- step ----
-  int mode, k, npred, nkm1, nkp1, maxit, lte_valid;
+  int mode, k, npred, nkm1, nkp1, maxit, inline_vals;
   double alpha[8], wpred[8], wkm1[8], wkp1[8];
   double ck, ckm1, ckp1;
   double abstol, reltol, newton_tol, dc_abstol, dv_max, gshunt;
+  double vals_inline[KV_INLINE];             // [kv | srcv] when they fit and are sample-independent
   // ---- outputs ----
   BlockOut* out;
+  Summary* summary;                          // output of reduce_blocks_kernel (mapped pinned host memory)
+  double* rate;                              // [n_comp*S] last observed Newton convergence rate per block
+  int reset_rate;                            // 1: ignore the stored rates (after a restart / failure)
+  double* obs_row;                           // [n_obs][S] candidate row of the observable buffer, or null
   double* dumpA; double* dumpF; double* dumpQ; int dump_stride;  // MODE_EVAL: per-block dense dumps
+  unsigned long long* stamps;                // diagnostic build (-DCH_STAMPS): [block][8] cycle sums, else null
 };
+
+#ifdef CH_STAMPS
+#define CH_STAMP(slot) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); acc_[slot] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define CH_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -82,18 +99,45 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// broadcast from a wave-uniform lane: v_readlane_b32 x2 (result lives in SGPRs)
+__device__ __forceinline__ double bcast(double v, int src_lane) {
+  const int l = __builtin_amdgcn_readfirstlane(src_lane);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 
-// Evaluate one device and write its 40-slot stamp record.
-__device__ __forceinline__ void eval_device(const NewtonArgs& a, int s, int d, const double* xl, int uofs, double* st) {
+// What the evaluation phase needs from the launch arguments (passed in registers to the
+// non-inlined evaluator, so that its register allocation is independent of the solve phase).
+struct EvalCtx {
+  const int* dkind; const int* dterm; const int* dsrc; const int* dcls_local; const int* dhdev;
+  const double* dpar; const double* dmult;
+  int Spar;
+  double gmin;
+};
+
+// Evaluate one lane slot of the device-evaluation phase.  slot = (local device << 2) | sub-lane.
+__device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int slot, const double* xl, int uofs,
+                                          const double* kvl, const double* svl, const double* pl, double* stage) {
+  const int dl = slot >> 2;
+  const int d = dofs + dl;
+  double* st = stage + (size_t)dl * 40;
   const int kind = a.dkind[d];
   const int* tm = a.dterm + 4 * d;
-  const double* kvs = a.kv + (long)(a.Ssrc > 1 ? s : 0) * a.nk;
   double v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { const int t = tm[k]; v[k] = t >= 0 ? xl[t - uofs] : kvs[-t - 1]; }
+  for (int k = 0; k < 4; ++k) { const int t = tm[k]; v[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
   const int hd = a.dhdev[d];
   const long pi = (long)hd * a.Spar + (a.Spar > 1 ? s : 0);
   const double m = a.dmult[pi];
+  if (kind == K_MOS) {
+    // parameters come from the block's LDS copy of its classes' packed columns (staged in the prologue)
+    const B4Col P{pl + (size_t)a.dcls_local[d] * B4I_COUNT};
+    double o[40];
+    b4_device(P, v[0], v[1], v[2], v[3], a.gmin, o);
+#pragma unroll
+    for (int j = 0; j < 40; ++j) st[j] = m * o[j];
+    return;
+  }
   switch (kind) {
     case K_R: {
       const double g = m / a.dpar[pi], i = g * (v[0] - v[1]);
@@ -108,13 +152,13 @@ __device__ __forceinline__ void eval_device(const NewtonArgs& a, int s, int d, c
       st[24] = c; st[25] = -c; st[28] = -c; st[29] = c;
     } break;
     case K_I: {
-      const double i = m * a.srcv[(long)(a.Ssrc > 1 ? s : 0) * a.nsrc + a.dsrc[d]];
+      const double i = m * svl[a.dsrc[d]];
       st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
     } break;
     case K_V: case K_L: case K_VCVS_A: {
       // terminals (a, b, branch): KCL rows get ±m·i, branch row: va - vb - V(t) [- d/dt(L i)]
       const double ib = v[2];
-      const double src = kind == K_V ? a.srcv[(long)(a.Ssrc > 1 ? s : 0) * a.nsrc + a.dsrc[d]] : 0.0;
+      const double src = kind == K_V ? svl[a.dsrc[d]] : 0.0;
       const double l = kind == K_L ? a.dpar[pi] : 0.0;
       st[0] = m * ib; st[1] = -m * ib; st[2] = v[0] - v[1] - src;
       st[4] = 0.0; st[5] = 0.0; st[6] = -l * ib;
@@ -133,20 +177,115 @@ __device__ __forceinline__ void eval_device(const NewtonArgs& a, int s, int d, c
       st[8 + 2] = g; st[8 + 3] = -g; st[8 + 6] = -g; st[8 + 7] = g;
       st[24 + 2] = 0.0; st[24 + 3] = 0.0; st[24 + 6] = 0.0; st[24 + 7] = 0.0;
     } break;
-    case K_MOS: {
-      B4Col P{a.mosp, a.mos_cols, (long)a.dcls[d] * a.Smos + (a.Smos > 1 ? s : 0)};
-      double o[40];
-      b4_device(P, v[0], v[1], v[2], v[3], a.gmin_s[a.Sgmin > 1 ? s : 0], o);
-#pragma unroll
-      for (int j = 0; j < 40; ++j) st[j] = m * o[j];
-    } break;
   }
 }
 
-// LDS layout (doubles): st[ndev_max*40] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq dx w qn [8*nc]
-__global__ __launch_bounds__(64) void newton_block_kernel(const NewtonArgs a) {
+// ---- DPP reductions over the 16-lane rows of a wavefront (no LDS round trip, ~8 cycles a step) ----
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QP_1032 = 0xB1, DPP_QP_2301 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+// result valid in every lane of rows 0 (NCV <= 16) or 0 and 1 (NCV == 32)
+template <int NCV> __device__ __forceinline__ double row_max(double v) {
+  v = fmax(v, dpp_d<DPP_QP_1032>(v)); v = fmax(v, dpp_d<DPP_QP_2301>(v));
+  v = fmax(v, dpp_d<DPP_HALF_MIRROR>(v)); v = fmax(v, dpp_d<DPP_MIRROR>(v));
+  if (NCV > 16) v = fmax(v, __shfl_xor(v, 16));
+  return v;
+}
+template <int NCV> __device__ __forceinline__ double row_sum(double v) {
+  v += dpp_d<DPP_QP_1032>(v); v += dpp_d<DPP_QP_2301>(v); v += dpp_d<DPP_HALF_MIRROR>(v); v += dpp_d<DPP_MIRROR>(v);
+  if (NCV > 16) v += __shfl_xor(v, 16);
+  return v;
+}
+template <int NCV> __device__ __forceinline__ int row_min_i(int v) {
+  v = min(v, dpp_i<DPP_QP_1032>(v)); v = min(v, dpp_i<DPP_QP_2301>(v)); v = min(v, dpp_i<DPP_HALF_MIRROR>(v)); v = min(v, dpp_i<DPP_MIRROR>(v));
+  if (NCV > 16) v = min(v, __shfl_xor(v, 16));
+  return v;
+}
+
+// In-register dense LU with partial pivoting + solve by ONE wavefront: lane i owns row i of the
+// augmented matrix [A | rhs] (r[0..NC], column indices are compile-time constants).  Pivot rows
+// are not moved: a lane that has served as pivot is retired and its row is broadcast with
+// v_readlane; the pivot search is a DPP max/min reduction.  Returns false when a pivot is zero or
+// not finite.  On return lane i holds x_i in `sol` (i < nc).
+template <int NC>
+__device__ __forceinline__ bool lu_solve_regs(double (&r)[NC + 1], int nc, int lane, double& sol) {
+  bool done = lane >= nc;
+  int mystep = -1;       // elimination step at which this lane's row became the pivot row
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    if (k < nc) {
+      const double av = done ? -1.0 : fabs(r[k]);
+      const double m = row_max<NC>(av);
+      const double m0 = bcast(m, 0);
+      if (!(m0 > 0.0) || !(m0 < 1e300)) return false;
+      const int bi = __builtin_amdgcn_readfirstlane(row_min_i<NC>(av == m0 ? lane : 64));
+      const double ipk = frcp(bcast(r[k], bi));
+      const double l = (!done && lane != bi) ? r[k] * ipk : 0.0;
+#pragma unroll
+      for (int j = k + 1; j <= NC; ++j) r[j] = fma(-l, bcast(r[j], bi), r[j]);
+      if (lane == bi) { done = true; mystep = k; }
+    }
+  }
+  // back substitution: x_k lives in lane piv_lane[k]; broadcast and eliminate from the earlier pivot rows
+  double rhs = 0.0;
+#pragma unroll
+  for (int j = 0; j <= NC; ++j) if (j == nc) rhs = r[j];
+  double x_of_step = 0.0;
+#pragma unroll
+  for (int k = NC - 1; k >= 0; --k) {
+    if (k < nc) {
+      const int pl = __ffsll((unsigned long long)__ballot(mystep == k)) - 1;  // the lane whose row was the k-th pivot
+      const double xk = bcast(rhs, pl) * frcp(bcast(r[k], pl));
+      if (mystep == k) x_of_step = xk;
+      else if (mystep >= 0 && mystep < k) rhs = fma(-r[k], xk, rhs);
+    }
+  }
+  double out = 0.0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) if (k < nc) { const double xk = bcast(x_of_step, __ffsll((unsigned long long)__ballot(mystep == k)) - 1); if (lane == k) out = xk; }
+  sol = out;
+  return true;
+}
+
+// LDS fallback for blocks larger than the register variant (single wave, barriers are wave-local fences)
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+__device__ inline bool lu_solve_lds(double* A, int lda, int nc, int lane) {
+  for (int k = 0; k < nc; ++k) {
+    double best = -1.0; int bi = k;
+    for (int i = k + lane; i < nc; i += 64) { const double v = fabs(A[i * lda + k]); if (v > best) { best = v; bi = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (!(best > 0.0) || !(best < 1e300)) return false;
+    if (bi != k) { for (int j = lane; j <= nc; j += 64) { const double t = A[k * lda + j]; A[k * lda + j] = A[bi * lda + j]; A[bi * lda + j] = t; } wave_fence(); }
+    const double inv = 1.0 / A[k * lda + k];
+    const int rem = nc - k - 1, w = rem + 1;
+    for (int i = k + 1 + lane; i < nc; i += 64) A[i * lda + k] *= inv;
+    wave_fence();
+    for (int e = lane; e < rem * w; e += 64) { const int i = k + 1 + e / w, j = k + 1 + e % w; A[i * lda + j] -= A[i * lda + k] * A[k * lda + j]; }
+    wave_fence();
+  }
+  for (int k = nc - 1; k >= 0; --k) {
+    const double xk = A[k * lda + nc] / A[k * lda + k];
+    wave_fence();
+    if (lane == 0) A[k * lda + nc] = xk;
+    for (int i = lane; i < k; i += 64) A[i * lda + nc] -= A[i * lda + k] * xk;
+    wave_fence();
+  }
+  return true;
+}
+
+// LDS layout (doubles): st[ndev*40] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq dx w qn [8*nc] | kvl[nk] svl[nsrc]
+//                       | ints: mptr[nc*nc+1] vptr[nc+1] slots[nslots] | u16: msrc[] vsrc[]
+template <int NC>
+__global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a) {
   extern __shared__ double lds[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
   const int c = blk / a.S, s = blk - c * a.S;
   const ClassMeta cm = a.classes[a.comp_class[c]];
@@ -158,173 +297,278 @@ __global__ __launch_bounds__(64) void newton_block_kernel(const NewtonArgs a) {
   double* xl = Cm + (size_t)nc * nc;
   double* xp = xl + nc; double* Fv = xp + nc; double* Qv = Fv + nc; double* hq = Qv + nc;
   double* dxv = hq + nc; double* wv = dxv + nc; double* qn = wv + nc;
-  const int* mptr = a.gl_ptr + cm.mat_ptr_ofs; const uint16_t* msrc = a.gl_src + cm.mat_src_ofs;
-  const int* vptr = a.gl_ptr + cm.vec_ptr_ofs; const uint16_t* vsrc = a.gl_src + cm.vec_src_ofs;
+  double* kvl = qn + nc; double* svl = kvl + a.nk;
+  double* pl = svl + a.nsrc;                       // [max_mc][B4I_COUNT] packed BSIM4 columns of this block's classes
+  int* mptr = (int*)(pl + (size_t)a.max_mc * B4I_COUNT);
+  int* vptr = mptr + (nc * nc + 1);
+  int* slots = vptr + (nc + 1);
+  int* mcl = slots + cm.nslots;                    // [64] this block's MOS class list
+  uint16_t* msrc = (uint16_t*)(mcl + 64);
+  uint16_t* vsrc = msrc + cm.n_mat_src;
+  __shared__ int s_ctl[4];  // [0] loop control (0 continue, 1 stop), [1] status, [2] iters
+  __shared__ double s_fnorm;
   const long sofs = (long)s * a.n_unk + uofs;
   const double* X0 = a.X + (long)a.hist_slot[0] * a.slot_stride + sofs;
-  BlockOut bo; bo.status = 1; bo.iters = 0; bo.ndiff = 0; bo.pad = 0; bo.e2k = bo.e2km1 = bo.e2kp1 = 0.0; bo.fnorm = 0.0;
+  const bool is_active = !(a.active && !a.active[blk]);
+#ifdef CH_STAMPS
+  unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
 
-  if (a.active && !a.active[blk]) {  // DC restart pass: this block already converged
-    return;
-  }
-  // ---- prologue ----
-  for (int i = lane; i < nc; i += 64) {
-    double x0 = X0[i];
-    double p = x0, h = 0.0;
-    if (a.mode == MODE_TRAN) {
-      p = 0.0;
-      for (int j = 0; j < a.npred; ++j) p += a.wpred[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i];
-      for (int j = 1; j <= a.k; ++j) h += a.alpha[j] * a.Qh[(long)a.hist_slot[j - 1] * a.slot_stride + sofs + i];
-    }
-    xp[i] = p; xl[i] = p; hq[i] = h;
-    wv[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
-  }
-  __syncthreads();
-  const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
-  int status = 1, iters = 0;
-  double fnorm = 0.0;
-  const int maxit = a.mode == MODE_EVAL ? 1 : a.maxit;
-  for (int it = 0; it <= maxit; ++it) {
-    // (1) device evaluation → staging
-    for (int d = lane; d < ndev; d += 64) eval_device(a, s, dofs + d, xl, uofs, st + (size_t)d * 40);
-    __syncthreads();
-    // (2) gather
-    for (int e = lane; e < nc * nc; e += 64) {
-      double g = 0.0, cc = 0.0;
-      for (int p = mptr[e]; p < mptr[e + 1]; ++p) { const int o = msrc[p]; g += st[o]; cc += st[o + 16]; }
-      const int r = e / nc, col = e - r * nc;
-      if (r == col && a.gshunt != 0.0 && !(a.dmask[uofs + r] & 2)) g += a.gshunt;  // node rows only
-      A[r * lda + col] = g + alpha0 * cc;
-      Cm[e] = cc;
-    }
-    for (int i = lane; i < nc; i += 64) {
-      double f = 0.0, q = 0.0;
-      for (int p = vptr[i]; p < vptr[i + 1]; ++p) { const int o = vsrc[p]; f += st[o]; q += st[o + 4]; }
-      if (a.gshunt != 0.0 && !(a.dmask[uofs + i] & 2)) f += a.gshunt * xl[i];
-      Qv[i] = q;
-      const double F = f + alpha0 * q + hq[i];
-      Fv[i] = F;
-      A[i * lda + nc] = -F;
-    }
-    __syncthreads();
-    if (a.mode == MODE_EVAL) {
-      if (a.dumpA) {
-        double* dA = a.dumpA + (long)blk * a.dump_stride * a.dump_stride;
-        for (int e = lane; e < nc * nc; e += 64) dA[e] = A[(e / nc) * lda + (e % nc)];
-        for (int i = lane; i < nc; i += 64) { a.dumpF[(long)blk * a.dump_stride + i] = Fv[i]; a.dumpQ[(long)blk * a.dump_stride + i] = Qv[i]; }
-      }
-      for (int i = lane; i < nc; i += 64) qn[i] = Qv[i];
-      status = 0;
-      break;
-    }
-    // residual norm (DC convergence test happens on the residual, src/dcop.jl:171-173)
+  if (is_active) {
+    // ---- prologue: stage lists / known values / BSIM4 columns in LDS, predictor and history term ----
+    // All global loads of one level are issued before any is consumed (batches of 8 per thread), so
+    // the prologue costs a few memory latencies instead of one per element.
     {
-      double m = 0.0;
-      for (int i = lane; i < nc; i += 64) m = fmax(m, fabs(Fv[i]));
-      fnorm = wave_max(m);
-    }
-    if (!(fnorm == fnorm) || fnorm > 1e300) { status = 2; break; }
-    if (a.mode == MODE_DC && fnorm < a.dc_abstol) { for (int i = lane; i < nc; i += 64) qn[i] = Qv[i]; status = 0; break; }
-    if (it == maxit) break;
-    // (3) LU with partial pivoting on the augmented matrix [A | -F] in LDS
-    bool singular = false;
-    for (int k = 0; k < nc; ++k) {
-      // pivot search over rows k..nc-1 of column k
-      double best = -1.0; int bi = k;
-      for (int i = k + lane; i < nc; i += 64) { const double v = fabs(A[i * lda + k]); if (v > best) { best = v; bi = i; } }
+      const int nmc = a.comp_mc_n[c], mco = a.comp_mc_ofs[c];
+      if (tid < nmc) mcl[tid] = a.mc_list[mco + tid];
+      auto copy_i = [&](int* dst, const int* src, int n) {
+        for (int base = tid; base < n; base += nthr * 8) {
+          int v[8];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; v[u] = i < n ? src[i] : 0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; if (i < n) dst[i] = v[u]; }
+        }
+      };
+      auto copy_h = [&](uint16_t* dst, const uint16_t* src, int n) {
+        for (int base = tid; base < n; base += nthr * 8) {
+          uint16_t v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; v[u] = i < n ? src[i] : (uint16_t)0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; if (i < n) dst[i] = v[u]; }
+        }
+      };
+      copy_i(mptr, a.gl_ptr + cm.mat_ptr_ofs, nc * nc + 1);
+      copy_i(vptr, a.gl_ptr + cm.vec_ptr_ofs, nc + 1);
+      copy_h(msrc, a.gl_src + cm.mat_src_ofs, cm.n_mat_src);
+      copy_h(vsrc, a.gl_src + cm.vec_src_ofs, cm.n_vec_src);
+      copy_i(slots, a.slot_tab + cm.slot_ofs, cm.nslots);
+      if (a.inline_vals) {
+#pragma unroll
+        for (int i = 0; i < KV_INLINE; ++i) if (tid == i && i < a.nk + a.nsrc) kvl[i] = a.vals_inline[i];  // kvl and svl are contiguous
+      } else {
+        const double* kg = a.kv + (long)(a.Ssrc > 1 ? s : 0) * a.nk;
+        const double* sg = a.srcv + (long)(a.Ssrc > 1 ? s : 0) * a.nsrc;
+        for (int i = tid; i < a.nk; i += nthr) kvl[i] = kg[i];
+        for (int i = tid; i < a.nsrc; i += nthr) svl[i] = sg[i];
       }
-      if (!(best > 0.0)) { singular = true; break; }
-      if (bi != k) {
-        for (int j = lane; j <= nc; j += 64) { const double t = A[k * lda + j]; A[k * lda + j] = A[bi * lda + j]; A[bi * lda + j] = t; }
-        __syncthreads();
+      __syncthreads();  // mcl visible
+      const int total = nmc * B4I_COUNT;
+      const long scol = a.Smos > 1 ? s : 0;
+      for (int base = tid; base < total; base += nthr * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = base + u * nthr;
+          if (e < total) { const int j = e / B4I_COUNT, i = e - j * B4I_COUNT; v[u] = a.mosp[((long)mcl[j] * a.Smos + scol) * (long)B4I_COUNT + i]; } else v[u] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = base + u * nthr; if (e < total) pl[e] = v[u]; }
       }
-      const double inv = 1.0 / A[k * lda + k];
-      const int rem = nc - k - 1;
-      // multipliers
-      for (int i = k + 1 + lane; i < nc; i += 64) A[i * lda + k] *= inv;
-      __syncthreads();
-      // rank-1 update of the trailing block and the rhs column
-      const int w = rem + 1;  // columns k+1..nc (incl. rhs)
-      for (int e = lane; e < rem * w; e += 64) {
-        const int i = k + 1 + e / w, j = k + 1 + e % w;
-        A[i * lda + j] -= A[i * lda + k] * A[k * lda + j];
+    }
+    for (int i = tid; i < nc; i += nthr) {
+      double x0 = X0[i];
+      double p = x0, h = 0.0;
+      if (a.mode == MODE_TRAN) {
+        p = 0.0;
+        for (int j = 0; j < a.npred; ++j) p += a.wpred[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i];
+        for (int j = 1; j <= a.k; ++j) h += a.alpha[j] * a.Qh[(long)a.hist_slot[j - 1] * a.slot_stride + sofs + i];
       }
-      __syncthreads();
+      xp[i] = p; xl[i] = p; hq[i] = h; qn[i] = 0.0;
+      wv[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
     }
-    if (singular) { status = 2; break; }
-    // back substitution on the rhs column
-    for (int k = nc - 1; k >= 0; --k) {
-      const double xk = A[k * lda + nc] / A[k * lda + k];
-      __syncthreads();
-      if (lane == 0) A[k * lda + nc] = xk;
-      for (int i = lane; i < k; i += 64) A[i * lda + nc] -= A[i * lda + k] * xk;
-      __syncthreads();
-    }
-    ++iters;
-    // (4) update
-    double scale = 1.0;
-    if (a.mode == MODE_DC && a.dv_max > 0.0 && cm.nonlinear) {  // linear blocks take the full Newton step
-      double m = 0.0;
-      for (int i = lane; i < nc; i += 64) if (!(a.dmask[uofs + i] & 2)) m = fmax(m, fabs(A[i * lda + nc]));
-      m = wave_max(m);
-      if (m > a.dv_max) scale = a.dv_max / m;
-    }
-    double e2 = 0.0; bool bad = false;
-    for (int i = lane; i < nc; i += 64) {
-      const double dx = scale * A[i * lda + nc];
-      dxv[i] = dx;
-      const double xn = xl[i] + dx;
-      xl[i] = xn;
-      if (!(xn == xn) || fabs(xn) > 1e300) bad = true;
-      const double t = dx * wv[i];
-      e2 += t * t;
-    }
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 1; s_ctl[2] = 0; }
     __syncthreads();
-    if (a.mode == MODE_TRAN) {
+    CH_STAMP(0);
+    const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
+    const int maxit = a.mode == MODE_EVAL ? 1 : a.maxit;
+    const double rate_prev = (a.mode == MODE_TRAN && !a.reset_rate) ? a.rate[blk] : 1.0;
+    double rate_new = -1.0, dn_prev = 0.0;  // wave 0 only
+    const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0]};
+    for (int it = 0; it <= maxit; ++it) {
+      // (1) device evaluation → staging (all waves)
+      for (int q = tid; q < cm.nslots; q += nthr) { const int sl = slots[q]; if (sl >= 0) eval_slot(ectx, s, dofs, sl, xl, uofs, kvl, svl, pl, st); }
+      __syncthreads();
+      CH_STAMP(1);
+      // (2) gather (all waves)
+      for (int e = tid; e < nc * nc; e += nthr) {
+        double g = 0.0, cc = 0.0;
+        for (int p = mptr[e]; p < mptr[e + 1]; ++p) { const int o = msrc[p]; g += st[o]; cc += st[o + 16]; }
+        const int r = e / nc, col = e - r * nc;
+        if (r == col && a.gshunt != 0.0 && !(a.dmask[uofs + r] & 2)) g += a.gshunt;  // node rows only
+        A[r * lda + col] = g + alpha0 * cc;
+        Cm[e] = cc;
+      }
+      for (int i = tid; i < nc; i += nthr) {
+        double f = 0.0, q = 0.0;
+        for (int p = vptr[i]; p < vptr[i + 1]; ++p) { const int o = vsrc[p]; f += st[o]; q += st[o + 4]; }
+        if (a.gshunt != 0.0 && !(a.dmask[uofs + i] & 2)) f += a.gshunt * xl[i];
+        Qv[i] = q;
+        const double F = f + alpha0 * q + hq[i];
+        Fv[i] = F;
+        A[i * lda + nc] = -F;
+      }
+      __syncthreads();
+      CH_STAMP(2);
+      // (3)+(4) solve, update, convergence: wave 0 only.  Register variant (nc <= NC): lane i keeps
+      // row i of [A | -F], row i of C, F_i, Q_i, x_i in VGPRs; reductions are DPP; no LDS round trips.
+      if (wave == 0) {
+        int status = 1, stop = 0;
+        const bool regs = (NC > 0 && nc <= NC);
+        if (a.mode == MODE_EVAL) {
+          if (a.dumpA) {
+            double* dA = a.dumpA + (long)blk * a.dump_stride * a.dump_stride;
+            for (int e = lane; e < nc * nc; e += 64) dA[e] = A[(e / nc) * lda + (e % nc)];
+            for (int i = lane; i < nc; i += 64) { a.dumpF[(long)blk * a.dump_stride + i] = Fv[i]; a.dumpQ[(long)blk * a.dump_stride + i] = Qv[i]; }
+          }
+          for (int i = lane; i < nc; i += 64) qn[i] = Qv[i];
+          status = 0; stop = 1;
+        } else if (regs) {
+          constexpr int NCR = NC > 0 ? NC : 1;
+          const bool mine = lane < nc;
+          double r[NCR + 1], cr[NCR];
+#pragma unroll
+          for (int j = 0; j <= NCR; ++j) r[j] = (mine && j <= nc) ? A[lane * lda + j] : 0.0;
+#pragma unroll
+          for (int j = 0; j < NCR; ++j) cr[j] = (mine && j < nc) ? Cm[lane * nc + j] : 0.0;
+          const double Fi = mine ? Fv[lane] : 0.0, Qi = mine ? Qv[lane] : 0.0, xi = mine ? xl[lane] : 0.0, wi = mine ? wv[lane] : 0.0;
+          const bool is_node = mine && !(a.dmask[uofs + (mine ? lane : 0)] & 2);
+          const double fnorm = bcast(row_max<NCR>(fabs(Fi)), 0);
+          if (lane == 0) s_fnorm = fnorm;
+          CH_STAMP(6);
+          if (!(fnorm == fnorm) || fnorm > 1e300) { status = 2; stop = 1; }
+          else if (a.mode == MODE_DC && fnorm < a.dc_abstol) { if (mine) qn[lane] = Qi; status = 0; stop = 1; }
+          else if (it == maxit) { stop = 1; }
+          else {
+            double dx = 0.0;
+            const bool ok = lu_solve_regs<NCR>(r, nc, lane, dx);
+            CH_STAMP(7);
+            if (!ok) { status = 2; stop = 1; }
+            else {
+              if (a.mode == MODE_DC && a.dv_max > 0.0 && cm.nonlinear) {  // linear blocks take the full Newton step
+                const double mm = bcast(row_max<NCR>(is_node ? fabs(dx) : 0.0), 0);
+                if (mm > a.dv_max) dx *= a.dv_max / mm;
+              }
+              const double xn = xi + dx;
+              if (mine) xl[lane] = xn;
+              const bool bad = mine && (!(xn == xn) || fabs(xn) > 1e300);
+              const double t = dx * wi;
+              const double e2 = bcast(row_sum<NCR>(mine ? t * t : 0.0), 0);
+              if (a.mode == MODE_TRAN) {
+                double q = Qi;
+#pragma unroll
+                for (int j = 0; j < NCR; ++j) if (j < nc) q = fma(cr[j], bcast(dx, j), q);
+                if (mine) qn[lane] = q;
+              }
+              if (lane == 0) s_ctl[2] += 1;
+              if (__ballot(bad)) { status = 2; stop = 1; }
+              else if (a.mode == MODE_TRAN) {
+                // IDA-style rate test: see oracle.cpp (same policy)
+                const double dn = sqrt(e2 / nc);
+                if (it == 0) { if (dn <= a.newton_tol || (rate_prev < 0.9 && 2.0 * fmax(rate_prev, 0.02) * dn <= a.newton_tol)) { status = 0; stop = 1; } }
+                else { rate_new = dn_prev > 0.0 ? dn / dn_prev : 0.0; if (dn <= a.newton_tol) { status = 0; stop = 1; } }
+                dn_prev = dn;
+              }
+            }
+          }
+        } else {
+          double m = 0.0;
+          for (int i = lane; i < nc; i += 64) m = fmax(m, fabs(Fv[i]));
+          const double fnorm = wave_max(m);
+          if (lane == 0) s_fnorm = fnorm;
+          if (!(fnorm == fnorm) || fnorm > 1e300) { status = 2; stop = 1; }
+          else if (a.mode == MODE_DC && fnorm < a.dc_abstol) { for (int i = lane; i < nc; i += 64) qn[i] = Qv[i]; status = 0; stop = 1; }
+          else if (it == maxit) { stop = 1; }
+          else {
+            const bool ok = lu_solve_lds(A, lda, nc, lane);
+            if (!ok) { status = 2; stop = 1; }
+            else {
+              double scale = 1.0;
+              if (a.mode == MODE_DC && a.dv_max > 0.0 && cm.nonlinear) {
+                double mm = 0.0;
+                for (int i = lane; i < nc; i += 64) if (!(a.dmask[uofs + i] & 2)) mm = fmax(mm, fabs(A[i * lda + nc]));
+                mm = wave_max(mm);
+                if (mm > a.dv_max) scale = a.dv_max / mm;
+              }
+              double e2 = 0.0; bool bad = false;
+              for (int i = lane; i < nc; i += 64) {
+                const double dx = scale * A[i * lda + nc];
+                dxv[i] = dx;
+                const double xn = xl[i] + dx;
+                xl[i] = xn;
+                if (!(xn == xn) || fabs(xn) > 1e300) bad = true;
+                const double t = dx * wv[i];
+                e2 += t * t;
+              }
+              wave_fence();
+              if (a.mode == MODE_TRAN) {
+                for (int i = lane; i < nc; i += 64) {
+                  double q = Qv[i];
+                  for (int j = 0; j < nc; ++j) q += Cm[i * nc + j] * dxv[j];
+                  qn[i] = q;
+                }
+              }
+              e2 = wave_sum(e2);
+              if (lane == 0) s_ctl[2] += 1;
+              if (__ballot(bad)) { status = 2; stop = 1; }
+              else if (a.mode == MODE_TRAN) {
+                const double dn = sqrt(e2 / nc);
+                if (it == 0) { if (dn <= a.newton_tol || (rate_prev < 0.9 && 2.0 * fmax(rate_prev, 0.02) * dn <= a.newton_tol)) { status = 0; stop = 1; } }
+                else { rate_new = dn_prev > 0.0 ? dn / dn_prev : 0.0; if (dn <= a.newton_tol) { status = 0; stop = 1; } }
+                dn_prev = dn;
+              }
+            }
+          }
+        }
+        if (lane == 0) { s_ctl[0] = stop; s_ctl[1] = status; }
+      }
+      __syncthreads();
+      CH_STAMP(3);
+      if (s_ctl[0]) break;
+    }
+    // ---- epilogue ----
+    double* Xc = a.X + (long)a.cand_slot * a.slot_stride + sofs;
+    double* Qc = a.Qh + (long)a.cand_slot * a.slot_stride + sofs;
+    if (wave == 0) {
+      double e2k = 0.0, e2m = 0.0, e2p = 0.0; int nd = 0;
       for (int i = lane; i < nc; i += 64) {
-        double q = Qv[i];
-        for (int j = 0; j < nc; ++j) q += Cm[i * nc + j] * dxv[j];
-        qn[i] = q;
+        const double xn = xl[i];
+        Xc[i] = xn;
+        Qc[i] = qn[i];
+        if (a.obs_row) { const int ob = a.unk_obs[uofs + i]; if (ob >= 0) a.obs_row[(long)ob * a.S + s] = xn; }
+        if (a.mode == MODE_TRAN && (a.dmask[uofs + i] & 1)) {
+          const double x0 = X0[i];
+          const double w = 1.0 / (a.reltol * fmax(fabs(x0), fabs(xn)) + a.abstol);
+          ++nd;
+          double t = (xn - xp[i]) * w; e2k += t * t;
+          if (a.nkm1 > 0) { double p = 0.0; for (int j = 0; j < a.nkm1; ++j) p += a.wkm1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i]; t = (xn - p) * w; e2m += t * t; }
+          if (a.nkp1 > 0) { double p = 0.0; for (int j = 0; j < a.nkp1; ++j) p += a.wkp1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i]; t = (xn - p) * w; e2p += t * t; }
+        }
+      }
+      e2k = wave_sum(e2k); e2m = wave_sum(e2m); e2p = wave_sum(e2p);
+      nd = (int)wave_sum((double)nd);
+      if (lane == 0) {
+        BlockOut bo; bo.status = s_ctl[1]; bo.iters = s_ctl[2]; bo.ndiff = nd; bo.pad = 0; bo.e2k = e2k; bo.e2km1 = e2m; bo.e2kp1 = e2p; bo.fnorm = s_fnorm;
+        a.out[blk] = bo;
+        if (a.mode == MODE_TRAN && s_ctl[1] == 0) a.rate[blk] = s_ctl[2] >= 2 ? fmin(1.0, fmax(rate_new, 1e-4)) : fmin(1.0, rate_prev * 1.5);
       }
     }
-    e2 = wave_sum(e2);
-    const unsigned long long anybad = __ballot(bad);
-    if (anybad) { status = 2; break; }
-    if (a.mode == MODE_TRAN && sqrt(e2 / nc) <= a.newton_tol) { status = 0; __syncthreads(); break; }
-    __syncthreads();
   }
-  // ---- epilogue ----
-  double* Xc = a.X + (long)a.cand_slot * a.slot_stride + sofs;
-  double* Qc = a.Qh + (long)a.cand_slot * a.slot_stride + sofs;
-  double e2k = 0.0, e2m = 0.0, e2p = 0.0; int nd = 0;
-  for (int i = lane; i < nc; i += 64) {
-    const double xn = xl[i];
-    Xc[i] = xn;
-    Qc[i] = qn[i];
-    if (a.mode == MODE_TRAN && (a.dmask[uofs + i] & 1)) {
-      const double x0 = X0[i];
-      const double w = 1.0 / (a.reltol * fmax(fabs(x0), fabs(xn)) + a.abstol);
-      ++nd;
-      double t = (xn - xp[i]) * w; e2k += t * t;
-      if (a.nkm1 > 0) { double p = 0.0; for (int j = 0; j < a.nkm1; ++j) p += a.wkm1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i]; t = (xn - p) * w; e2m += t * t; }
-      if (a.nkp1 > 0) { double p = 0.0; for (int j = 0; j < a.nkp1; ++j) p += a.wkp1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i]; t = (xn - p) * w; e2p += t * t; }
-    }
-  }
-  e2k = wave_sum(e2k); e2m = wave_sum(e2m); e2p = wave_sum(e2p);
-  nd = (int)wave_sum((double)nd);
-  if (lane == 0) {
-    bo.status = status; bo.iters = iters; bo.ndiff = nd; bo.e2k = e2k; bo.e2km1 = e2m; bo.e2kp1 = e2p; bo.fnorm = fnorm;
-    a.out[blk] = bo;
-  }
+  CH_STAMP(4);
+  CH_STAMP(5);
+#ifdef CH_STAMPS
+  if (tid == 0 && a.stamps) for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], acc_[i]);
+#endif
 }
 
 // Reduce per-block outputs: WRMS per sample (over all blocks of the sample), max over samples.
 // Many samples: one thread per sample loops over the sample's blocks.  Few samples (a single large
-// circuit): the 256 threads split the blocks of one sample and tree-reduce in LDS.
+// circuit): the threads split the blocks of one sample and tree-reduce in LDS.
+// Used when there are many blocks; for up to a few thousand blocks the Newton kernel writes its
+// 48-byte BlockOut records straight into mapped pinned host memory and the HOST reduces them — no
+// second launch, no inter-block hand-off (an in-kernel last-block reduction was measured at
+// 8-12 us per launch for its agent-scope fences; profiles/r01_notes.md).
 struct RedAcc {
   double a, b, c, f; long long nd, bits; int nfail, nsing, mx;
 };
@@ -334,54 +578,61 @@ __device__ __forceinline__ void red_add(RedAcc& x, const BlockOut& o) {
   if (o.status == 2) ++x.nsing;
   x.mx = max(x.mx, o.iters); x.f = fmax(x.f, o.fnorm);
 }
-__global__ __launch_bounds__(256) void reduce_blocks_kernel(const BlockOut* out, int n_comp, int S, double ck, double ckm1, double ckp1,
-                                                            const unsigned char* active, Summary* sum) {
-  __shared__ double sk[256], sm[256], sp[256], sf[256];
-  __shared__ int sfail[256], smax[256], ssing[256];
-  __shared__ long long sit[256], sbi[256], snd[256];
-  const int t = threadIdx.x;
-  double mk_ = 0.0, mm = 0.0, mp = 0.0, mf = 0.0; int nfail = 0, mx = 0, nsing = 0; long long its = 0, bits = 0;
+__device__ inline void reduce_all_blocks(const NewtonArgs& a, int t, int T, double* red) {
+  // LDS scratch carved from the kernel's dynamic LDS (the Newton phase is over): 9 arrays of T doubles
+  double* sk = red; double* sm = sk + T; double* sp = sm + T; double* sf = sp + T;
+  double* snd = sf + T; double* sbi = snd + T; double* sfail = sbi + T; double* ssing = sfail + T; double* smax = ssing + T;
+  const BlockOut* out = a.out; const unsigned char* active = a.active;
+  const int n_comp = a.n_comp, S = a.S;
+  double mk_ = 0.0, mm = 0.0, mp = 0.0, mf = 0.0; double nfail = 0, mx = 0, nsing = 0, its = 0, bits = 0;
+  __syncthreads();
   if (S >= 64) {
-    for (int s = t; s < S; s += 256) {
+    for (int s = t; s < S; s += T) {
       RedAcc x{0, 0, 0, 0, 0, 0, 0, 0, 0};
       for (int k = 0; k < n_comp; ++k) { const int blk = k * S + s; if (active && !active[blk]) continue; red_add(x, out[blk]); }
-      its += x.mx; mx = max(mx, x.mx); nfail += x.nfail; nsing += x.nsing; bits += x.bits; mf = fmax(mf, x.f);
-      if (x.nd > 0) { mk_ = fmax(mk_, ck * sqrt(x.a / x.nd)); mm = fmax(mm, ckm1 * sqrt(x.b / x.nd)); mp = fmax(mp, ckp1 * sqrt(x.c / x.nd)); }
+      its += x.mx; mx = fmax(mx, (double)x.mx); nfail += x.nfail; nsing += x.nsing; bits += (double)x.bits; mf = fmax(mf, x.f);
+      if (x.nd > 0) { mk_ = fmax(mk_, a.ck * sqrt(x.a / x.nd)); mm = fmax(mm, a.ckm1 * sqrt(x.b / x.nd)); mp = fmax(mp, a.ckp1 * sqrt(x.c / x.nd)); }
     }
   } else {
     for (int s = 0; s < S; ++s) {
       RedAcc x{0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int k = t; k < n_comp; k += 256) { const int blk = k * S + s; if (active && !active[blk]) continue; red_add(x, out[blk]); }
-      sk[t] = x.a; sm[t] = x.b; sp[t] = x.c; sf[t] = x.f; snd[t] = x.nd; sbi[t] = x.bits; sfail[t] = x.nfail; ssing[t] = x.nsing; smax[t] = x.mx;
+      for (int k = t; k < n_comp; k += T) { const int blk = k * S + s; if (active && !active[blk]) continue; red_add(x, out[blk]); }
+      sk[t] = x.a; sm[t] = x.b; sp[t] = x.c; sf[t] = x.f; snd[t] = (double)x.nd; sbi[t] = (double)x.bits; sfail[t] = x.nfail; ssing[t] = x.nsing; smax[t] = x.mx;
       __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) {
+      for (int o = T >> 1; o > 0; o >>= 1) {
         if (t < o) {
           sk[t] += sk[t + o]; sm[t] += sm[t + o]; sp[t] += sp[t + o]; sf[t] = fmax(sf[t], sf[t + o]); snd[t] += snd[t + o]; sbi[t] += sbi[t + o];
-          sfail[t] += sfail[t + o]; ssing[t] += ssing[t + o]; smax[t] = max(smax[t], smax[t + o]);
+          sfail[t] += sfail[t + o]; ssing[t] += ssing[t + o]; smax[t] = fmax(smax[t], smax[t + o]);
         }
         __syncthreads();
       }
       if (t == 0) {
-        its += smax[0]; mx = max(mx, smax[0]); nfail += sfail[0]; nsing += ssing[0]; bits += sbi[0]; mf = fmax(mf, sf[0]);
-        if (snd[0] > 0) { mk_ = fmax(mk_, ck * sqrt(sk[0] / snd[0])); mm = fmax(mm, ckm1 * sqrt(sm[0] / snd[0])); mp = fmax(mp, ckp1 * sqrt(sp[0] / snd[0])); }
+        its += smax[0]; mx = fmax(mx, smax[0]); nfail += sfail[0]; nsing += ssing[0]; bits += sbi[0]; mf = fmax(mf, sf[0]);
+        if (snd[0] > 0) { mk_ = fmax(mk_, a.ck * sqrt(sk[0] / snd[0])); mm = fmax(mm, a.ckm1 * sqrt(sm[0] / snd[0])); mp = fmax(mp, a.ckp1 * sqrt(sp[0] / snd[0])); }
       }
       __syncthreads();
     }
   }
-  sk[t] = mk_; sm[t] = mm; sp[t] = mp; sf[t] = mf; sfail[t] = nfail; smax[t] = mx; ssing[t] = nsing; sit[t] = its; sbi[t] = bits;
+  sk[t] = mk_; sm[t] = mm; sp[t] = mp; sf[t] = mf; sfail[t] = nfail; smax[t] = mx; ssing[t] = nsing; snd[t] = its; sbi[t] = bits;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = T >> 1; o > 0; o >>= 1) {
     if (t < o) {
       sk[t] = fmax(sk[t], sk[t + o]); sm[t] = fmax(sm[t], sm[t + o]); sp[t] = fmax(sp[t], sp[t + o]); sf[t] = fmax(sf[t], sf[t + o]);
-      sfail[t] += sfail[t + o]; smax[t] = max(smax[t], smax[t + o]); ssing[t] += ssing[t + o]; sit[t] += sit[t + o]; sbi[t] += sbi[t + o];
+      sfail[t] += sfail[t + o]; smax[t] = fmax(smax[t], smax[t + o]); ssing[t] += ssing[t + o]; snd[t] += snd[t + o]; sbi[t] += sbi[t + o];
     }
     __syncthreads();
   }
   if (t == 0) {
-    Summary r; r.n_fail = sfail[0]; r.max_iters = smax[0]; r.n_singular = ssing[0]; r.pad = 0; r.sum_iters = sit[0]; r.sum_block_iters = sbi[0];
+    Summary r; r.n_fail = (int)sfail[0]; r.max_iters = (int)smax[0]; r.n_singular = (int)ssing[0]; r.pad = 0;
+    r.sum_iters = (long long)snd[0]; r.sum_block_iters = (long long)sbi[0];
     r.errk = sk[0]; r.errkm1 = sm[0]; r.errkp1 = sp[0]; r.fnorm = sf[0];
-    *sum = r;
+    *a.summary = r;
   }
+}
+
+__global__ __launch_bounds__(256) void reduce_blocks_kernel(const NewtonArgs a) {
+  extern __shared__ double rlds[];
+  reduce_all_blocks(a, threadIdx.x, blockDim.x, rlds);
 }
 
 // Save observables: out[o*S + s] = Σ_j w[j] X[slot_j][s][idx_o]  (idx < 0 → NaN placeholder, filled on host)
@@ -400,10 +651,20 @@ __global__ void save_obs_kernel(const ObsArgs a) {
 __global__ __launch_bounds__(64) void mos_eval_kernel(const double* mosp, long mos_cols, const int* cls, int Smos, int sample, int n_mos, const double* v, double gmin, double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_mos) return;
-  B4Col P{mosp, mos_cols, (long)cls[i] * Smos + (Smos > 1 ? sample : 0)};
+  const B4Col P = b4_col(mosp, (long)cls[i] * Smos + (Smos > 1 ? sample : 0));
   double o[40];
   b4_device(P, v[4 * i + 0], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], gmin, o);
   for (int j = 0; j < 40; ++j) out[(long)i * 40 + j] = o[j];
+}
+
+// Same evaluation with four lanes per instance (the path the Newton kernel uses); writes the
+// 40-slot records straight to `out` (multiplier 1).
+__global__ __launch_bounds__(64) void mos_eval_quad_kernel(const double* mosp, long mos_cols, const int* cls, int Smos, int sample, int n_mos, const double* v, double gmin, double* out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = q >> 2, sub = q & 3;
+  if (i >= n_mos) return;
+  const B4Col P = b4_col(mosp, (long)cls[i] * Smos + (Smos > 1 ? sample : 0));
+  b4_device_quad(P, v[4 * i + 0], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], gmin, sub, 1.0, out + (long)i * 40);
 }
 
 }  // namespace chip

@@ -12,7 +12,7 @@ import numpy as np
 from .circuit import (ChDcOpts, ChDesc, ChInfo, ChStats, ChTranOpts, CedarError, RETCODES, dc_opts, tran_opts)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcedarhip.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("CEDARHIP_LIB", "libcedarhip.so"))  # CEDARHIP_LIB: diagnostic builds
 _pf64 = C.POINTER(C.c_double)
 _pi32 = C.POINTER(C.c_int32)
 
@@ -20,7 +20,7 @@ EXPORTS = [
     "ch_dc_opts_default", "ch_tran_opts_default", "ch_create", "ch_destroy", "ch_last_error", "ch_circuit_build",
     "ch_circuit_free", "ch_circuit_info", "ch_circuit_maps", "ch_set_samples", "ch_set_params", "ch_dc", "ch_tran",
     "ch_result_n_times", "ch_result_times", "ch_result_values", "ch_result_final_state", "ch_result_stats",
-    "ch_result_status", "ch_result_free", "ch_eval", "ch_mos_eval", "ch_bsim4_npar", "ch_bsim4_param_name",
+    "ch_result_status", "ch_result_free", "ch_eval", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
     "ch_bsim4_param_ignored", "ch_version",
 ]
 
@@ -61,6 +61,7 @@ def load_library():
     L.ch_result_free.argtypes = [vp]
     L.ch_eval.argtypes = [vp, C.c_int32, _pf64, C.c_double, C.c_double, C.c_int32, _pf64, _pf64, _pf64]
     L.ch_mos_eval.argtypes = [vp, C.c_int32, _pf64, _pf64]
+    L.ch_mos_eval_quad.argtypes = [vp, C.c_int32, _pf64, _pf64]
     L.ch_bsim4_npar.restype = C.c_int32
     L.ch_bsim4_param_name.restype = C.c_char_p
     L.ch_bsim4_param_name.argtypes = [C.c_int32]
@@ -196,9 +197,10 @@ class EngineCircuit:
         self._check(self.L.ch_eval(self.h, sample, _p(x), t, alpha0, mode, _p(F), _p(Q), _p(J)), "ch_eval")
         return F, Q, J
 
-    def mos_eval(self, v, sample=0):
+    def mos_eval(self, v, sample=0, quad=False):
         v = np.ascontiguousarray(v, dtype=np.float64)
         nm = self.info()["n_mos"]
         out = np.zeros((nm, 40))
-        self._check(self.L.ch_mos_eval(self.h, sample, _p(v), _p(out)), "ch_mos_eval")
+        fn = self.L.ch_mos_eval_quad if quad else self.L.ch_mos_eval
+        self._check(fn(self.h, sample, _p(v), _p(out)), "ch_mos_eval")
         return out

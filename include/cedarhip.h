@@ -244,6 +244,9 @@ int ch_eval(ch_circuit*, int32_t sample, const double* x_mna, double t, double a
  *      given terminal voltages.  v: [n_mos][4] (d,g,s,b); out: [n_mos][40] =
  *      {i[4], q[4], g[16], c[16]} per instance.  Used by the parity tests and bench. ---- */
 int ch_mos_eval(ch_circuit*, int32_t sample, const double* v, double* out);
+/* Same result computed the way the Newton kernel does it: four lanes per instance, one partial
+ * derivative per lane, columns exchanged with quad shuffles. */
+int ch_mos_eval_quad(ch_circuit*, int32_t sample, const double* v, double* out);
 
 /* ---- names of BSIM4 parameters (for host-side card parsing) ---- */
 int32_t ch_bsim4_npar(void);

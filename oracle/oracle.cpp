@@ -473,6 +473,7 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
   h = std::min(h, (bps[0] - t0) / 50.0) * kFirstFrac;
   h = std::max(h, 10 * dtmin);
   int k = 1, steps_at_order = 0;
+  double newton_rate = 1.0;  // last observed Newton convergence rate (1 = unknown: forces two iterations)
   std::vector<double> xp(n), xn(n), dx(n), w(n), ev(n), A, hq(n), qn(n);
   std::vector<int> piv;
   double tau[8], alpha[8], wts[8];
@@ -507,6 +508,8 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
     // ---- Newton ----
     xn = xp;
     bool conv = false;
+    double dn_prev = 0.0, rate_new = -1.0;
+    int its_this = 0;
     for (int it = 0; it < nmaxit; ++it) {
       evaluate(c, xn.data(), tsrc, 1, e);
       R.stats.nf++; R.stats.njacs++;
@@ -521,11 +524,24 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
       if (!finite) break;
       // first-order consistent charge at the updated point: q(x+dx) ~ q(x) + C dx
       for (int i = 0; i < n; ++i) { double s = e.Q[i]; const double* ci = &e.C[(size_t)i * n]; for (int j = 0; j < n; ++j) s += ci[j] * dx[j]; qn[i] = s; }
-      if (wrms(dx, w) <= 0.1) { conv = true; break; }
+      // Convergence (IDA's rate test, IDANls): after the first iteration the remaining error is
+      // estimated from the convergence rate observed in earlier solves, so a well-predicted step
+      // needs ONE Newton iteration; the rate is refreshed whenever a second iteration runs and is
+      // aged (x1.5) otherwise, which forces a periodic two-iteration check.
+      const double dn = wrms(dx, w);
+      ++its_this;
+      if (it == 0) {
+        if (dn <= 0.1 || (newton_rate < 0.9 && 2.0 * std::max(newton_rate, 0.02) * dn <= 0.1)) { conv = true; break; }
+      } else {
+        rate_new = dn_prev > 0 ? dn / dn_prev : 0.0;
+        if (dn <= 0.1) { conv = true; break; }
+      }
+      dn_prev = dn;
     }
+    if (conv) newton_rate = its_this >= 2 ? std::min(1.0, std::max(rate_new, 1e-4)) : std::min(1.0, newton_rate * 1.5);
     if (!conv) {
       R.stats.nnonlinconvfail++;
-      h = hh * 0.25; k = 1; steps_at_order = 0;
+      h = hh * 0.25; k = 1; steps_at_order = 0; newton_rate = 1.0;
       if (hist.size() > 2) hist.resize(2);
       continue;
     }
@@ -595,7 +611,7 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
     if (hit_bp && t < t1) {
       // slope discontinuity: restart at order 1 from this point
       hist.resize(1);
-      k = 1; steps_at_order = 0;
+      k = 1; steps_at_order = 0; newton_rate = 1.0;
       double nb = t1;
       for (size_t b = ibp; b < bps.size(); ++b) if (bps[b] > t * (1 + 1e-15)) { nb = bps[b]; break; }
       h = std::max(dtmin * 10, std::min(h, (nb - t) / 50.0) * kFirstFrac);

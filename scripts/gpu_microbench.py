@@ -1,4 +1,4 @@
-"""Development script: stand-alone timing of the BSIM4 evaluation kernel (30720 instances)."""
+"""Development script: stand-alone timing of the BSIM4 evaluation kernels (30720 instances)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,4 +11,5 @@ rng = np.random.default_rng(0)
 v = rng.uniform(0, 5, size=(30720, 4))
 for i in range(20):
     out = e.mos_eval(v)
+    out = e.mos_eval(v, quad=True)
 print("ok", out.shape)

@@ -74,11 +74,13 @@ def test_bsim4_stamps_match_oracle(E, O):
         a, b = e.mos_eval(v), o.mos_eval(v)
         sc = np.maximum(np.abs(b).max(axis=0, keepdims=True), 1e-30)
         assert np.max(np.abs(a - b) / sc) < 1e-10
+        aq = e.mos_eval(v, quad=True)  # the 4-lanes-per-instance path used inside the Newton kernel
+        assert np.max(np.abs(aq - b) / sc) < 1e-10
     # edge cases: vds = 0 exactly, reverse mode, forward-biased junctions, deep subthreshold
     v = np.array([[2.0, 3.0, 2.0, 0.0], [0.5, 3.0, 4.0, 0.0], [0.0, 5.0, 0.0, 0.9], [5.0, -2.0, 0.0, 0.0]] + [[1, 1, 1, 1.0]] * 26)
-    a, b = e.mos_eval(v), o.mos_eval(v)
+    a, aq, b = e.mos_eval(v), e.mos_eval(v, quad=True), o.mos_eval(v)
     sc = np.maximum(np.abs(b).max(axis=0, keepdims=True), 1e-30)
-    assert np.max(np.abs(a - b) / sc) < 1e-10
+    assert np.max(np.abs(a - b) / sc) < 1e-10 and np.max(np.abs(aq - b) / sc) < 1e-10
 
 
 def test_residual_jacobian_assembly_matches_oracle(E, O):
