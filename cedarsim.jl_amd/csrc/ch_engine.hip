@@ -123,14 +123,38 @@ void extrap_weights(const double* tau, int np, double* w) {
   for (int j = 1; j <= np; ++j) { double v = 1; for (int i = 1; i <= np; ++i) if (i != j) v *= (tau[0] - tau[i]) / (tau[j] - tau[i]); w[j] = v; }
 }
 
+// All device buffers of a circuit are carved out of a few large allocations: the Newton kernel's
+// prologue touches a dozen different arrays, and with one hipMalloc per array every launch paid a
+// cold translation miss per array (measured: prologue 9 us -> see profiles/r01_notes.md).
+struct Arena {
+  std::vector<char*> chunks; size_t used = 0, cap = 0;
+  static constexpr size_t CHUNK = 32u << 20;
+  ~Arena() { for (char* c : chunks) (void)hipFree(c); }
+  void* take(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes > CHUNK / 2) { char* p = nullptr; if (hipMalloc((void**)&p, bytes) != hipSuccess) return nullptr; chunks.insert(chunks.begin(), p); return p; }
+    if (chunks.empty() || used + bytes > cap) { char* p = nullptr; if (hipMalloc((void**)&p, CHUNK) != hipSuccess) return nullptr; chunks.push_back(p); used = 0; cap = CHUNK; }
+    void* r = chunks.back() + used; used += bytes; return r;
+  }
+};
+static thread_local Arena* g_arena = nullptr;  // set while a circuit builds / rebuilds its buffers
+
 template <class T>
 struct DevBuf {
-  T* p = nullptr; size_t n = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; return hipMalloc((void**)&p, std::max<size_t>(1, count) * sizeof(T)); }
+  T* p = nullptr; size_t n = 0; bool owned = false;
+  ~DevBuf() { if (p && owned) (void)hipFree(p); }
+  hipError_t alloc(size_t count) {
+    if (p && count <= n && count > 0) { return hipSuccess; }  // reuse
+    if (p && owned) (void)hipFree(p);
+    p = nullptr; n = count;
+    const size_t bytes = std::max<size_t>(1, count) * sizeof(T);
+    if (g_arena) { p = (T*)g_arena->take(bytes); owned = false; return p ? hipSuccess : hipErrorOutOfMemory; }
+    owned = true;
+    return hipMalloc((void**)&p, bytes);
+  }
   hipError_t upload(const std::vector<T>& h, hipStream_t st) {
     hipError_t e = hipSuccess;
-    if (h.size() != n || !p) e = alloc(h.size());
+    if (h.size() > n || !p) e = alloc(h.size());
     if (e != hipSuccess) return e;
     if (h.empty()) return hipSuccess;
     e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
@@ -151,6 +175,7 @@ struct ch_result {
 };
 
 struct ch_circuit {
+  Arena arena;  // declared first: destroyed last, after every DevBuf that points into it
   ch_ctx* ctx = nullptr;
   // ---- description ----
   int n_nodes = 0;
@@ -173,6 +198,8 @@ struct ch_circuit {
   DevBuf<unsigned long long> d_stamps;
   std::vector<int> obs_primary;  // per observable: the observable whose device row it shares (itself if primary)
   DevBuf<int> d_mc_ofs, d_mc_n, d_mc_list, d_dcls_local;
+  DevBuf<BlockMeta> d_bmeta;
+  std::vector<ClassMeta> h_cms;
   int block_threads = 64, lu_variant = 16, max_mc = 0;
   bool host_reduce = true;      // block outputs land in mapped host memory and the host reduces them
   BlockOut* h_out = nullptr;    // mapped pinned [n_comp*S]
@@ -206,26 +233,30 @@ struct ch_circuit {
 
   // ------------------------------------------------------------------------------------------
   int upload_structure() {
+    g_arena = &arena;
     hipStream_t st = ctx->stream;
-    std::vector<ClassMeta> cms; std::vector<int> ptr, slot_tab; std::vector<uint16_t> srcs;
+    std::vector<ClassMeta> cms; std::vector<int> blob;
     int max_slots = 0;
     for (size_t ci = 0; ci < A.classes.size(); ++ci) {
       const CompClass& c = A.classes[ci];
       ClassMeta m; std::memset(&m, 0, sizeof(m));
       m.nc = c.nc; m.ndev = c.ndev; m.nonlinear = c.nonlinear ? 1 : 0;
-      m.mat_ptr_ofs = (int)ptr.size(); ptr.insert(ptr.end(), c.mat_ptr.begin(), c.mat_ptr.end());
-      m.vec_ptr_ofs = (int)ptr.size(); ptr.insert(ptr.end(), c.vec_ptr.begin(), c.vec_ptr.end());
-      m.mat_src_ofs = (int)srcs.size(); srcs.insert(srcs.end(), c.mat_src.begin(), c.mat_src.end());
-      m.vec_src_ofs = (int)srcs.size(); srcs.insert(srcs.end(), c.vec_src.begin(), c.vec_src.end());
       m.n_mat_src = (int)c.mat_src.size(); m.n_vec_src = (int)c.vec_src.size();
-      // lane slots of the evaluation phase
-      m.slot_ofs = (int)slot_tab.size();
+      // one contiguous blob per class, copied verbatim into LDS: mat_ptr | vec_ptr | slots | mat_src | vec_src
+      m.blob_ofs = (int)blob.size();
+      blob.insert(blob.end(), c.mat_ptr.begin(), c.mat_ptr.end());
+      blob.insert(blob.end(), c.vec_ptr.begin(), c.vec_ptr.end());
       int rep = -1;
       for (int k = 0; k < A.n_comp; ++k) if (A.comp_class[k] == (int)ci) { rep = k; break; }
+      int ns = 0;
       // one lane per device instance; MOSFETs first so that the expensive lanes share wavefronts
-      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind == K_MOS) slot_tab.push_back(d << 2);
-      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind != K_MOS) slot_tab.push_back(d << 2);
-      m.nslots = (int)slot_tab.size() - m.slot_ofs;
+      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind == K_MOS) { blob.push_back(d << 2); ++ns; }
+      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind != K_MOS) { blob.push_back(d << 2); ++ns; }
+      m.nslots = ns;
+      std::vector<uint16_t> h16(c.mat_src); h16.insert(h16.end(), c.vec_src.begin(), c.vec_src.end());
+      if (h16.size() & 1) h16.push_back(0);
+      for (size_t i = 0; i < h16.size(); i += 2) blob.push_back((int)((uint32_t)h16[i] | ((uint32_t)h16[i + 1] << 16)));
+      m.blob_ints = (int)blob.size() - m.blob_ofs;
       max_slots = std::max(max_slots, m.nslots);
       cms.push_back(m);
     }
@@ -246,9 +277,10 @@ struct ch_circuit {
       if (u >= 0) { if (unk_obs[u] < 0) unk_obs[u] = (int)o; else prim = unk_obs[u]; }
       obs_primary.push_back(prim);
     }
-    HIPCHK(d_unk_obs.upload(unk_obs, st)); HIPCHK(d_slot_tab.upload(slot_tab, st));
+    HIPCHK(d_unk_obs.upload(unk_obs, st));
     { std::vector<unsigned long long> z(8, 0ull); HIPCHK(d_stamps.upload(z, st)); }
-    HIPCHK(d_classes.upload(cms, st)); HIPCHK(d_gl_ptr.upload(ptr, st)); HIPCHK(d_gl_src.upload(srcs, st));
+    h_cms = cms;
+    HIPCHK(d_classes.upload(cms, st)); HIPCHK(d_gl_ptr.upload(blob, st));
     HIPCHK(d_comp_class.upload(A.comp_class, st)); HIPCHK(d_comp_uofs.upload(A.comp_uofs, st)); HIPCHK(d_comp_dofs.upload(A.comp_dofs, st));
     HIPCHK(d_dkind.upload(dkind, st)); HIPCHK(d_dterm.upload(dterm, st)); HIPCHK(d_dsrc.upload(dsrc, st)); HIPCHK(d_dhdev.upload(dhdev, st));
     HIPCHK(d_dmask.upload(dm, st)); HIPCHK(d_obs_unk.upload(obs_unk, st));
@@ -259,8 +291,7 @@ struct ch_circuit {
     for (size_t ci = 0; ci < A.classes.size(); ++ci) {
       const CompClass& c = A.classes[ci];
       lds_doubles_fixed = std::max(lds_doubles_fixed, (size_t)c.ndev * 40 + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 8 * (size_t)c.nc);
-      const size_t ints = (size_t)c.nc * c.nc + 1 + c.nc + 1 + cms[ci].nslots + 64;  // + scratch for the block's MOS class list
-      lds_extra_bytes = std::max(lds_extra_bytes, ints * 4 + (c.mat_src.size() + c.vec_src.size()) * 2 + 16);
+      lds_extra_bytes = std::max(lds_extra_bytes, ((size_t)cms[ci].blob_ints + 64) * 4 + 16);  // blob + the block's MOS class list
     }
     return CH_OK;
   }
@@ -272,6 +303,7 @@ struct ch_circuit {
   // (Re)build all per-sample parameter tables: remake(prob, p = sim) for every sample at once.
   int finalize_params() {
     if (!dirty) return CH_OK;
+    g_arena = &arena;
     hipStream_t st = ctx->stream;
     const int nslot = (int)slot_kind.size();
     bool any_par = false, any_src = false, any_mos = false, any_gmin = false;
@@ -367,6 +399,13 @@ struct ch_circuit {
         max_mc = std::max(max_mc, mc_n[k]);
       }
       if (max_mc > 64) { set_err("a Jacobian block uses more than 64 distinct MOSFET classes"); return CH_ERR_UNSUPPORTED; }
+      std::vector<BlockMeta> bmv(A.n_comp);
+      for (int k = 0; k < A.n_comp; ++k) {
+        BlockMeta& b = bmv[k]; std::memset(&b, 0, sizeof(b));
+        b.uofs = A.comp_uofs[k]; b.dofs = A.comp_dofs[k]; b.mc_n = mc_n[k]; b.mc_ofs = mc_ofs[k]; b.cm = h_cms[A.comp_class[k]];
+        for (int j = 0; j < mc_n[k] && j < 8; ++j) b.mc[j] = mc_list[mc_ofs[k] + j];
+      }
+      HIPCHK(d_bmeta.upload(bmv, st));
       HIPCHK(d_mc_ofs.upload(mc_ofs, st)); HIPCHK(d_mc_n.upload(mc_n, st)); HIPCHK(d_mc_list.upload(mc_list, st)); HIPCHK(d_dcls_local.upload(dloc, st));
     }
     HIPCHK(d_moscls_inst.upload(mos_cls, st));
@@ -391,14 +430,14 @@ struct ch_circuit {
     NewtonArgs& a = base;
     std::memset(&a, 0, sizeof(a));
     a.comp_class = d_comp_class.p; a.comp_uofs = d_comp_uofs.p; a.comp_dofs = d_comp_dofs.p; a.classes = d_classes.p;
-    a.gl_ptr = d_gl_ptr.p; a.gl_src = d_gl_src.p; a.dkind = d_dkind.p; a.dterm = d_dterm.p; a.dsrc = d_dsrc.p; a.dcls = d_dcls.p; a.dhdev = d_dhdev.p;
+    a.blob = d_gl_ptr.p; a.dkind = d_dkind.p; a.dterm = d_dterm.p; a.dsrc = d_dsrc.p; a.dcls = d_dcls.p; a.dhdev = d_dhdev.p;
     a.dpar = d_dpar.p; a.dmult = d_dmult.p; a.mosp = d_mosp.p; a.mos_cols = cols; a.kv = d_kv.p; a.srcv = d_kv.p + (size_t)Ssrc * A.known.size(); a.dmask = d_dmask.p;
     a.active = nullptr; a.gmin_s = d_gmin.p;
     a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = std::max(1, nsrc);
     a.n_unk = A.n_unk; a.n_mos_cls = n_cls;
     a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = host_reduce ? h_out : d_out.p;
-    a.slot_tab = d_slot_tab.p; a.unk_obs = d_unk_obs.p; a.n_obs = (int)obs_kind.size();
-    a.dcls_local = d_dcls_local.p; a.comp_mc_ofs = d_mc_ofs.p; a.comp_mc_n = d_mc_n.p; a.mc_list = d_mc_list.p; a.max_mc = max_mc;
+    a.unk_obs = d_unk_obs.p; a.n_obs = (int)obs_kind.size();
+    a.bmeta = d_bmeta.p; a.dcls_local = d_dcls_local.p; a.comp_mc_ofs = d_mc_ofs.p; a.comp_mc_n = d_mc_n.p; a.mc_list = d_mc_list.p; a.max_mc = max_mc;
     a.summary = h_sum; a.rate = d_rate.p;
 #ifdef CH_STAMPS
     a.stamps = d_stamps.p;
@@ -932,6 +971,7 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
   if (!c || !x_mna || sample < 0 || sample >= c->S) return CH_ERR_INVALID;
   c->ctx->err.clear();
   (void)hipSetDevice(c->ctx->device);
+  g_arena = &c->arena;
   int rc = c->finalize_params();
   if (rc != CH_OK) return rc;
   const Analysis& A = c->A;

@@ -26,7 +26,15 @@ namespace chip {
 struct ClassMeta {
   int nc, ndev, nonlinear, nslots;   // nslots: lane slots of the evaluation phase (4 per MOSFET, 1 otherwise)
   int mat_ptr_ofs, mat_src_ofs, vec_ptr_ofs, vec_src_ofs;  // offsets into the pooled gather arrays
-  int n_mat_src, n_vec_src, slot_ofs, pad;                  // list lengths; offset into the slot table
+  int n_mat_src, n_vec_src, blob_ofs, blob_ints;            // list lengths; this class's packed list blob (ints)
+};
+
+// Everything a block needs to address its data, in ONE 96-byte record (one dependent load level):
+// offsets, a copy of its class record and (when they are at most 8) its MOS class ids.
+struct BlockMeta {
+  int uofs, dofs, mc_n, mc_ofs;
+  ClassMeta cm;
+  int mc[8];
 };
 
 struct BlockOut {
@@ -51,8 +59,9 @@ constexpr int KV_INLINE = 24;
 
 struct NewtonArgs {
   // ---- circuit structure ----
+  const BlockMeta* bmeta;                    // [n_comp]
   const int* comp_class; const int* comp_uofs; const int* comp_dofs;
-  const ClassMeta* classes; const int* gl_ptr; const uint16_t* gl_src; const int* slot_tab;
+  const ClassMeta* classes; const int* blob;  // per class: [mat_ptr | vec_ptr | slots | mat_src u16 | vec_src u16], copied verbatim to LDS
   const int* dkind; const int* dterm; const int* dsrc; const int* dcls; const int* dhdev;
   const int* dcls_local;                     // per device: index into its block's MOS class list
   const int* comp_mc_ofs; const int* comp_mc_n; const int* mc_list;  // per block: distinct MOS classes
@@ -288,8 +297,9 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
   const int c = blk / a.S, s = blk - c * a.S;
-  const ClassMeta cm = a.classes[a.comp_class[c]];
-  const int nc = cm.nc, ndev = cm.ndev, uofs = a.comp_uofs[c], dofs = a.comp_dofs[c];
+  const BlockMeta bm = a.bmeta[c];
+  const ClassMeta cm = bm.cm;
+  const int nc = cm.nc, ndev = cm.ndev, uofs = bm.uofs, dofs = bm.dofs;
   const int lda = nc + 1;
   double* st = lds;
   double* A = st + (size_t)ndev * 40;
@@ -299,12 +309,12 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
   double* dxv = hq + nc; double* wv = dxv + nc; double* qn = wv + nc;
   double* kvl = qn + nc; double* svl = kvl + a.nk;
   double* pl = svl + a.nsrc;                       // [max_mc][B4I_COUNT] packed BSIM4 columns of this block's classes
-  int* mptr = (int*)(pl + (size_t)a.max_mc * B4I_COUNT);
+  int* mptr = (int*)(pl + (size_t)a.max_mc * B4I_COUNT);  // start of the class blob copy
   int* vptr = mptr + (nc * nc + 1);
   int* slots = vptr + (nc + 1);
-  int* mcl = slots + cm.nslots;                    // [64] this block's MOS class list
-  uint16_t* msrc = (uint16_t*)(mcl + 64);
+  uint16_t* msrc = (uint16_t*)(slots + cm.nslots);
   uint16_t* vsrc = msrc + cm.n_mat_src;
+  int* mcl = mptr + cm.blob_ints;                  // [64] this block's MOS class list (behind the blob)
   __shared__ int s_ctl[4];  // [0] loop control (0 continue, 1 stop), [1] status, [2] iters
   __shared__ double s_fnorm;
   const long sofs = (long)s * a.n_unk + uofs;
@@ -319,31 +329,23 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
     // All global loads of one level are issued before any is consumed (batches of 8 per thread), so
     // the prologue costs a few memory latencies instead of one per element.
     {
-      const int nmc = a.comp_mc_n[c], mco = a.comp_mc_ofs[c];
-      if (tid < nmc) mcl[tid] = a.mc_list[mco + tid];
-      auto copy_i = [&](int* dst, const int* src, int n) {
+      const int nmc = bm.mc_n, mco = bm.mc_ofs;
+      if (nmc <= 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (tid == j && j < nmc) mcl[j] = bm.mc[j];
+      } else if (tid < nmc) mcl[tid] = a.mc_list[mco + tid];
+      // the class's gather lists and slot table: one contiguous int blob, one batch of loads
+      {
+        const int* src = a.blob + cm.blob_ofs;
+        const int n = cm.blob_ints;
         for (int base = tid; base < n; base += nthr * 8) {
           int v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; v[u] = i < n ? src[i] : 0; }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; if (i < n) dst[i] = v[u]; }
+          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; if (i < n) mptr[i] = v[u]; }
         }
-      };
-      auto copy_h = [&](uint16_t* dst, const uint16_t* src, int n) {
-        for (int base = tid; base < n; base += nthr * 8) {
-          uint16_t v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; v[u] = i < n ? src[i] : (uint16_t)0; }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; if (i < n) dst[i] = v[u]; }
-        }
-      };
-      copy_i(mptr, a.gl_ptr + cm.mat_ptr_ofs, nc * nc + 1);
-      copy_i(vptr, a.gl_ptr + cm.vec_ptr_ofs, nc + 1);
-      copy_h(msrc, a.gl_src + cm.mat_src_ofs, cm.n_mat_src);
-      copy_h(vsrc, a.gl_src + cm.vec_src_ofs, cm.n_vec_src);
-      copy_i(slots, a.slot_tab + cm.slot_ofs, cm.nslots);
+      }
       if (a.inline_vals) {
 #pragma unroll
         for (int i = 0; i < KV_INLINE; ++i) if (tid == i && i < a.nk + a.nsrc) kvl[i] = a.vals_inline[i];  // kvl and svl are contiguous
@@ -356,24 +358,32 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       __syncthreads();  // mcl visible
       const int total = nmc * B4I_COUNT;
       const long scol = a.Smos > 1 ? s : 0;
-      for (int base = tid; base < total; base += nthr * 8) {
-        double v[8];
+      constexpr int PB = 18;  // 8 DFF classes x 137 doubles / 64 lanes = 17.1: one batch of loads in flight
+      for (int base = tid; base < total; base += nthr * PB) {
+        double v[PB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < PB; ++u) {
           const int e = base + u * nthr;
           if (e < total) { const int j = e / B4I_COUNT, i = e - j * B4I_COUNT; v[u] = a.mosp[((long)mcl[j] * a.Smos + scol) * (long)B4I_COUNT + i]; } else v[u] = 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = base + u * nthr; if (e < total) pl[e] = v[u]; }
+        for (int u = 0; u < PB; ++u) { const int e = base + u * nthr; if (e < total) pl[e] = v[u]; }
       }
     }
     for (int i = tid; i < nc; i += nthr) {
       double x0 = X0[i];
       double p = x0, h = 0.0;
       if (a.mode == MODE_TRAN) {
+        double xv[7], qv[5];  // all history loads are issued before any is used
+#pragma unroll
+        for (int j = 0; j < 7; ++j) xv[j] = j < a.npred ? a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) qv[j] = j < a.k ? a.Qh[(long)a.hist_slot[j] * a.slot_stride + sofs + i] : 0.0;
         p = 0.0;
-        for (int j = 0; j < a.npred; ++j) p += a.wpred[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i];
-        for (int j = 1; j <= a.k; ++j) h += a.alpha[j] * a.Qh[(long)a.hist_slot[j - 1] * a.slot_stride + sofs + i];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) p += a.wpred[j + 1] * xv[j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) h += a.alpha[j + 1] * qv[j];
       }
       xp[i] = p; xl[i] = p; hq[i] = h; qn[i] = 0.0;
       wv[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
