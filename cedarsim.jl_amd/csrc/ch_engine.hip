@@ -191,6 +191,9 @@ struct ch_circuit {
   bool dirty = true;
   int Spar = 1, Ssrc = 1, Smos = 1, Sgmin = 1;
   std::vector<double> h_src_dc, h_src_par;  // [Ssrc][nsrc], [Ssrc][nsrc][8]
+  std::vector<int> needed_src;              // sources that define a known node or feed a surviving device (others, e.g. merged 0 V ammeters, are never evaluated)
+  std::vector<int> dev_src;                 // sources whose value the kernels read (referenced by a surviving V / I device)
+  int n_dev_src() const { return std::max<int>(1, (int)dev_src.size()); }
   std::vector<int> mos_cls;                 // [n_mos]
   int n_cls = 0;
   // ---- device buffers ----
@@ -263,7 +266,19 @@ struct ch_circuit {
     block_threads = std::min(256, std::max(64, ((max_slots + 63) / 64) * 64));
     lu_variant = A.max_nc <= 8 ? 8 : (A.max_nc <= 12 ? 12 : (A.max_nc <= 16 ? 16 : (A.max_nc <= 32 ? 32 : 0)));
     std::vector<int> dkind, dterm, dsrc, dhdev;
-    for (const EDev& e : A.edev) { dkind.push_back(e.kind); for (int k = 0; k < 4; ++k) dterm.push_back(e.term[k]); dsrc.push_back(e.src < 0 ? 0 : e.src); dhdev.push_back(e.hdev); }
+    dev_src.clear();
+    { std::vector<int> slot_of(src.size(), -1);
+      for (const EDev& e : A.edev) {
+        dkind.push_back(e.kind); for (int k = 0; k < 4; ++k) dterm.push_back(e.term[k]); dhdev.push_back(e.hdev);
+        int si = 0;
+        if (e.src >= 0) { if (slot_of[e.src] < 0) { slot_of[e.src] = (int)dev_src.size(); dev_src.push_back(e.src); } si = slot_of[e.src]; }
+        dsrc.push_back(si);
+      }
+      std::vector<char> need(src.size(), 0);
+      for (int si : dev_src) need[si] = 1;
+      for (const KnownDef& kd : A.known) for (auto& tm : kd.terms) need[tm.first] = 1;
+      needed_src.clear();
+      for (size_t i = 0; i < src.size(); ++i) if (need[i]) needed_src.push_back((int)i); }
     std::vector<unsigned char> dm(A.n_unk, 0);
     for (int u = 0; u < A.n_unk; ++u) dm[u] = (A.diff_mask[u] ? 1 : 0) | (A.unk_mna[u] >= n_nodes ? 2 : 0);
     std::vector<int> obs_unk, unk_obs(A.n_unk, -1);
@@ -423,7 +438,7 @@ struct ch_circuit {
       h_out_n = (size_t)A.n_comp * S;
     }
     HIPCHK(d_active.alloc((size_t)A.n_comp * S));
-    const size_t need = (size_t)Ssrc * (A.known.size() + std::max(1, nsrc));
+    const size_t need = (size_t)Ssrc * (A.known.size() + n_dev_src());
     HIPCHK(d_kv.alloc(need));  // [kv | srcv] contiguous: one upload per step
     if (need > h_stage_n) { if (h_stage) (void)hipHostFree(h_stage); HIPCHK(hipHostMalloc((void**)&h_stage, need * sizeof(double))); h_stage_n = need; }
     // argument template
@@ -433,7 +448,7 @@ struct ch_circuit {
     a.blob = d_gl_ptr.p; a.dkind = d_dkind.p; a.dterm = d_dterm.p; a.dsrc = d_dsrc.p; a.dcls = d_dcls.p; a.dhdev = d_dhdev.p;
     a.dpar = d_dpar.p; a.dmult = d_dmult.p; a.mosp = d_mosp.p; a.mos_cols = cols; a.kv = d_kv.p; a.srcv = d_kv.p + (size_t)Ssrc * A.known.size(); a.dmask = d_dmask.p;
     a.active = nullptr; a.gmin_s = d_gmin.p;
-    a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = std::max(1, nsrc);
+    a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = n_dev_src();
     a.n_unk = A.n_unk; a.n_mos_cls = n_cls;
     a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = host_reduce ? h_out : d_out.p;
     a.unk_obs = d_unk_obs.p; a.n_obs = (int)obs_kind.size();
@@ -442,7 +457,7 @@ struct ch_circuit {
 #ifdef CH_STAMPS
     a.stamps = d_stamps.p;
 #endif
-    lds_bytes = (lds_doubles_fixed + A.known.size() + std::max(1, nsrc) + (size_t)max_mc * B4I_COUNT) * sizeof(double) + lds_extra_bytes;
+    lds_bytes = (lds_doubles_fixed + A.known.size() + n_dev_src() + (size_t)max_mc * B4I_COUNT) * sizeof(double) + lds_extra_bytes;
     lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
     if (lds_bytes > 156 * 1024) { set_err("a Jacobian block needs more LDS than one CU has; the sparse path for large coupled blocks is not built yet"); return CH_ERR_UNSUPPORTED; }
     if (lds_bytes > 48 * 1024) {
@@ -458,16 +473,17 @@ struct ch_circuit {
   }
 
   // host evaluation of source and known-node values for sample set s at time t
+  mutable std::vector<double> all_src;
   void eval_sources(double t, int mode, std::vector<double>& sv, std::vector<double>& kv) const {
-    const int nsrc = (int)src.size(), nk = (int)A.known.size();
-    sv.assign((size_t)Ssrc * std::max(1, nsrc), 0.0); kv.assign((size_t)Ssrc * nk, 0.0);
+    const int nsrc = (int)src.size(), nk = (int)A.known.size(), nds = n_dev_src();
+    sv.assign((size_t)Ssrc * nds, 0.0); kv.assign((size_t)Ssrc * nk, 0.0);
+    all_src.resize(std::max(1, nsrc));
     for (int s = 0; s < Ssrc; ++s) {
-      for (int i = 0; i < nsrc; ++i) sv[(size_t)s * std::max(1, nsrc) + i] = source_value(src[i], &h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR], h_src_dc[(size_t)s * nsrc + i], t, mode);
-      for (int k = 0; k < nk; ++k) { double v = 0; for (auto& tm : A.known[k].terms) v += tm.second * sv[(size_t)s * std::max(1, nsrc) + tm.first]; kv[(size_t)s * nk + k] = v; }
+      for (int i : needed_src) all_src[i] = source_value(src[i], &h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR], h_src_dc[(size_t)s * nsrc + i], t, mode);
+      for (size_t j = 0; j < dev_src.size(); ++j) sv[(size_t)s * nds + j] = all_src[dev_src[j]];
+      for (int k = 0; k < nk; ++k) { double v = 0; for (auto& tm : A.known[k].terms) v += tm.second * all_src[tm.first]; kv[(size_t)s * nk + k] = v; }
     }
   }
-  // Source / known-node values for the next launch: passed inside the kernel arguments when they are
-  // sample-independent and few (no H2D copy at all), otherwise one small upload.
   std::vector<double> sv_buf, kv_buf;
   int set_sources(NewtonArgs& a, double t, int mode) {
     std::vector<double>& sv = sv_buf; std::vector<double>& kv = kv_buf;
