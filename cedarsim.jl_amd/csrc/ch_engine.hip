@@ -23,6 +23,7 @@
 #include "ch_analysis.hpp"
 #include "ch_bsim4.hpp"
 #include "ch_kernels.hpp"
+#include "ch_sparse.hpp"
 
 using namespace chip;
 using hclock = std::chrono::steady_clock;
@@ -220,6 +221,16 @@ struct ch_circuit {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   size_t lds_bytes = 0, lds_doubles_fixed = 0, lds_extra_bytes = 0;
   NewtonArgs base;              // structure pointers filled once
+  // ---- sparse path (blocks too large for LDS) ----
+  int path = 1;                 // 1 = fused block kernel, 2 = sparse level-scheduled LU
+  SparsePlan plan[2];           // [0] DC (alpha0 = 0), [1] transient
+  struct PlanDev { DevBuf<int> prow, pcol, a2lu, diag_pos, lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows, lrow_ptr, l_pos, l_k, l_upd_ptr, upd_dst, upd_src, urow_ptr, u_pos, u_col; DevBuf<double> LUv; } plan_dev[2];
+  DevBuf<int> sp_dflag;
+  DevBuf<int> sp_rowptr, sp_colidx, sp_mat_gptr, sp_mat_gsrc, sp_vec_gptr, sp_vec_gsrc;
+  DevBuf<double> sp_stage, sp_Aval, sp_Cval, sp_F, sp_Q, sp_rhs, sp_y, sp_dx, sp_xcur, sp_xpred, sp_hq, sp_w, sp_qn;
+  std::vector<int> h_rowptr, h_colidx;
+  double* h_red = nullptr; int* h_flag = nullptr;  // mapped pinned
+  double sp_rate = 1.0;
   // stats
   double device_ms = 0; long n_launch = 0, n_timed = 0;  // device_ms sums the sampled launches only
 
@@ -229,6 +240,8 @@ struct ch_circuit {
   ~ch_circuit() {
     if (h_sum) (void)hipHostFree(h_sum);
     if (h_out) (void)hipHostFree(h_out);
+    if (h_red) (void)hipHostFree(h_red);
+    if (h_flag) (void)hipHostFree(h_flag);
     if (h_stage) (void)hipHostFree(h_stage);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -413,7 +426,7 @@ struct ch_circuit {
         mc_list.insert(mc_list.end(), seen.begin(), seen.end());
         max_mc = std::max(max_mc, mc_n[k]);
       }
-      if (max_mc > 64) { set_err("a Jacobian block uses more than 64 distinct MOSFET classes"); return CH_ERR_UNSUPPORTED; }
+      if (max_mc > 64 && false) { set_err("a Jacobian block uses more than 64 distinct MOSFET classes"); return CH_ERR_UNSUPPORTED; }
       std::vector<BlockMeta> bmv(A.n_comp);
       for (int k = 0; k < A.n_comp; ++k) {
         BlockMeta& b = bmv[k]; std::memset(&b, 0, sizeof(b));
@@ -434,6 +447,8 @@ struct ch_circuit {
     host_reduce = (size_t)A.n_comp * S <= 4096 && std::getenv("CEDARHIP_DEVICE_REDUCE") == nullptr;
     if (host_reduce && h_out_n < (size_t)A.n_comp * S) {
       if (h_out) (void)hipHostFree(h_out);
+    if (h_red) (void)hipHostFree(h_red);
+    if (h_flag) (void)hipHostFree(h_flag);
       HIPCHK(hipHostMalloc((void**)&h_out, (size_t)A.n_comp * S * sizeof(BlockOut), hipHostMallocMapped));
       h_out_n = (size_t)A.n_comp * S;
     }
@@ -459,8 +474,14 @@ struct ch_circuit {
 #endif
     lds_bytes = (lds_doubles_fixed + A.known.size() + n_dev_src() + (size_t)max_mc * B4I_COUNT) * sizeof(double) + lds_extra_bytes;
     lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
-    if (lds_bytes > 156 * 1024) { set_err("a Jacobian block needs more LDS than one CU has; the sparse path for large coupled blocks is not built yet"); return CH_ERR_UNSUPPORTED; }
-    if (lds_bytes > 48 * 1024) {
+    path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
+    if (path == 2) {
+      if (S != 1) { set_err("the sparse path (Jacobian blocks larger than one CU's LDS) handles one sample at a time"); return CH_ERR_UNSUPPORTED; }
+      int rcs = build_sparse_structure();
+      if (rcs != CH_OK) return rcs;
+      lds_bytes = 0;
+    }
+    if (path == 1 && lds_bytes > 48 * 1024) {
       HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -503,8 +524,164 @@ struct ch_circuit {
   }
 
   // launch the fused Newton kernel + reduction and wait for the summary
+  // ------------------------------------------------------------------------------------------
+  // Sparse path: CSR pattern + gather lists over the global unknown numbering
+  int build_sparse_structure() {
+    hipStream_t st = ctx->stream;
+    const int n = A.n_unk, nd = (int)A.edev.size();
+    std::vector<std::map<int, std::vector<int>>> rows(n);
+    std::vector<std::vector<int>> vrows(n);
+    for (int d = 0; d < nd; ++d) {
+      const EDev& e = A.edev[d];
+      bool vm[4], mm[16]; kind_mask(e.kind, vm, mm);
+      for (int k = 0; k < 4; ++k) if (vm[k] && e.term[k] >= 0) vrows[e.term[k]].push_back(d * 40 + k);
+      for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j) if (mm[k * 4 + j] && e.term[k] >= 0 && e.term[j] >= 0) rows[e.term[k]][e.term[j]].push_back(d * 40 + 8 + k * 4 + j);
+    }
+    for (int i = 0; i < n; ++i) rows[i][i];  // structural diagonal (gmin stepping, pivots)
+    h_rowptr.assign(1, 0); h_colidx.clear();
+    std::vector<int> mgp(1, 0), mgs, vgp(1, 0), vgs;
+    for (int i = 0; i < n; ++i) {
+      for (auto& kv : rows[i]) { h_colidx.push_back(kv.first); mgs.insert(mgs.end(), kv.second.begin(), kv.second.end()); mgp.push_back((int)mgs.size()); }
+      h_rowptr.push_back((int)h_colidx.size());
+      vgs.insert(vgs.end(), vrows[i].begin(), vrows[i].end()); vgp.push_back((int)vgs.size());
+    }
+    const size_t nnz = h_colidx.size();
+    HIPCHK(sp_rowptr.upload(h_rowptr, st)); HIPCHK(sp_colidx.upload(h_colidx, st)); HIPCHK(sp_mat_gptr.upload(mgp, st)); HIPCHK(sp_mat_gsrc.upload(mgs, st));
+    HIPCHK(sp_vec_gptr.upload(vgp, st)); HIPCHK(sp_vec_gsrc.upload(vgs, st));
+    HIPCHK(sp_stage.alloc((size_t)nd * 40)); HIPCHK(sp_Aval.alloc(nnz)); HIPCHK(sp_Cval.alloc(nnz));
+    for (DevBuf<double>* b : {&sp_F, &sp_Q, &sp_rhs, &sp_y, &sp_dx, &sp_xcur, &sp_xpred, &sp_hq, &sp_w, &sp_qn}) HIPCHK(b->alloc(n));
+    if (!h_red) { HIPCHK(hipHostMalloc((void**)&h_red, 8 * sizeof(double), hipHostMallocMapped)); HIPCHK(hipHostMalloc((void**)&h_flag, 2 * sizeof(int), hipHostMallocMapped)); }
+    { std::vector<int> z(2, 0); HIPCHK(sp_dflag.upload(z, st)); }
+    plan[0].valid = plan[1].valid = false;
+    return CH_OK;
+  }
+  SparseDev sparse_dev(int which) {
+    SparseDev d; std::memset(&d, 0, sizeof(d));
+    PlanDev& pd = plan_dev[which]; const SparsePlan& P = plan[which];
+    d.rowptr = sp_rowptr.p; d.colidx = sp_colidx.p; d.mat_gptr = sp_mat_gptr.p; d.mat_gsrc = sp_mat_gsrc.p; d.vec_gptr = sp_vec_gptr.p; d.vec_gsrc = sp_vec_gsrc.p;
+    d.prow = pd.prow.p; d.pcol = pd.pcol.p; d.a2lu = pd.a2lu.p; d.diag_pos = pd.diag_pos.p; d.lvl_ptr = pd.lvl_ptr.p; d.lvl_rows = pd.lvl_rows.p;
+    d.ulvl_ptr = pd.ulvl_ptr.p; d.ulvl_rows = pd.ulvl_rows.p; d.lrow_ptr = pd.lrow_ptr.p; d.l_pos = pd.l_pos.p; d.l_k = pd.l_k.p; d.l_upd_ptr = pd.l_upd_ptr.p;
+    d.upd_dst = pd.upd_dst.p; d.upd_src = pd.upd_src.p; d.urow_ptr = pd.urow_ptr.p; d.u_pos = pd.u_pos.p; d.u_col = pd.u_col.p;
+    d.n = A.n_unk; d.nnz = (int)h_colidx.size(); d.nnz_lu = P.nnz_lu; d.n_lvl = P.valid ? (int)P.lvl_ptr.size() - 1 : 0; d.n_ulvl = P.valid ? (int)P.ulvl_ptr.size() - 1 : 0; d.n_dev = (int)A.edev.size();
+    d.stage = sp_stage.p; d.Aval = sp_Aval.p; d.Cval = sp_Cval.p; d.LUv = pd.LUv.p; d.F = sp_F.p; d.Q = sp_Q.p; d.rhs = sp_rhs.p; d.y = sp_y.p; d.dx = sp_dx.p;
+    d.xcur = sp_xcur.p; d.xpred = sp_xpred.p; d.hq = sp_hq.p; d.w = sp_w.p; d.qn = sp_qn.p; d.red = h_red; d.flag = h_flag; d.dflag = sp_dflag.p;
+    return d;
+  }
+  // host analysis from the current numeric values of A (KLU-style: analyse once, refactor many times)
+  int sparse_plan_from_current(int which) {
+    g_arena = &arena;
+    hipStream_t st = ctx->stream;
+    std::vector<double> aval(h_colidx.size());
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(aval.data(), sp_Aval.p, aval.size() * sizeof(double), hipMemcpyDeviceToHost));
+    SparsePlan& P = plan[which];
+    int rc = sparse_analyse(A.n_unk, h_rowptr, h_colidx, aval, P);
+    if (rc != CH_OK) { set_err("sparse analysis: structurally singular Jacobian"); return rc; }
+    PlanDev& pd = plan_dev[which];
+    HIPCHK(pd.prow.upload(P.prow, st)); HIPCHK(pd.pcol.upload(P.pcol, st)); HIPCHK(pd.a2lu.upload(P.a2lu, st)); HIPCHK(pd.diag_pos.upload(P.diag_pos, st));
+    HIPCHK(pd.lvl_ptr.upload(P.lvl_ptr, st)); HIPCHK(pd.lvl_rows.upload(P.lvl_rows, st)); HIPCHK(pd.ulvl_ptr.upload(P.ulvl_ptr, st)); HIPCHK(pd.ulvl_rows.upload(P.ulvl_rows, st));
+    HIPCHK(pd.lrow_ptr.upload(P.lrow_ptr, st)); HIPCHK(pd.l_pos.upload(P.l_pos, st)); HIPCHK(pd.l_k.upload(P.l_k, st)); HIPCHK(pd.l_upd_ptr.upload(P.l_upd_ptr, st));
+    HIPCHK(pd.upd_dst.upload(P.upd_dst, st)); HIPCHK(pd.upd_src.upload(P.upd_src, st)); HIPCHK(pd.urow_ptr.upload(P.urow_ptr, st)); HIPCHK(pd.u_pos.upload(P.u_pos, st)); HIPCHK(pd.u_col.upload(P.u_col, st));
+    HIPCHK(pd.LUv.alloc((size_t)P.nnz_lu));
+    return CH_OK;
+  }
+  int sp_sync() {
+    hipStream_t st = ctx->stream;
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 200000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(st);
+    if (q == hipErrorNotReady) q = hipStreamSynchronize(st);
+    if (q != hipSuccess) { set_err(std::string("sparse path: ") + hipGetErrorString(q)); return CH_ERR_DEVICE; }
+    return CH_OK;
+  }
+  // One Newton solve (same contract as the fused kernel: reads the history ring, writes the candidate slot)
+  int run_sparse(NewtonArgs a, Summary& out) {
+    const bool dbg = std::getenv("CEDARHIP_DEBUG") != nullptr;
+#define SPDBG(msg) do { if (dbg) { std::fprintf(stderr, "[sp] %s\n", msg); std::fflush(stderr); } } while (0)
+    SPDBG("enter");
+    hipStream_t st = ctx->stream;
+    const int which = a.mode == MODE_DC ? 0 : 1;
+    const int n = A.n_unk, nd = (int)A.edev.size(), nnz = (int)h_colidx.size();
+    // source values always through the device buffer on this path
+    if (a.inline_vals) {
+      std::memcpy(h_stage, a.vals_inline, (size_t)(a.nk + a.nsrc) * sizeof(double));
+      HIPCHK(hipMemcpyAsync(d_kv.p, h_stage, (size_t)(a.nk + a.nsrc) * sizeof(double), hipMemcpyHostToDevice, st));
+      a.inline_vals = 0;
+    }
+    SparseDev d = sparse_dev(which);
+    const dim3 b256(256), gn((n + 255) / 256), gd((nd + 63) / 64), ga((std::max(n, nnz) + 255) / 256);
+    std::memset(&out, 0, sizeof(out));
+    hipLaunchKernelGGL(sp_predict_kernel, gn, b256, 0, st, a, d);
+    SPDBG("predict launched");
+    const int maxit = a.mode == MODE_EVAL ? 0 : a.maxit;
+    const double rate_prev = (a.mode == MODE_TRAN && !a.reset_rate) ? sp_rate : 1.0;
+    double rate_new = -1.0, dn_prev = 0.0;
+    int status = 1, iters = 0;
+    double fnorm = 0.0;
+    for (int it = 0; it <= maxit; ++it) {
+      hipLaunchKernelGGL(sp_eval_kernel, gd, dim3(64), 0, st, a, d);
+      hipLaunchKernelGGL(sp_assemble_kernel, ga, b256, 0, st, a, d);
+      if (a.gshunt != 0.0) hipLaunchKernelGGL(sp_diag_shunt_kernel, gn, b256, 0, st, a, d);
+      n_launch += 2;
+      SPDBG("assembled");
+      if (a.mode == MODE_EVAL) { status = 0; break; }
+      if (a.mode == MODE_DC) {
+        hipLaunchKernelGGL(sp_norms_kernel, dim3(1), dim3(1024), 0, st, a, d, 0);
+        int rc = sp_sync(); if (rc != CH_OK) return rc;
+        fnorm = h_red[0];
+        if (!(fnorm == fnorm) || fnorm > 1e300) { status = 2; break; }
+        if (fnorm < a.dc_abstol) { status = 0; break; }
+      }
+      if (it == maxit) break;
+      SPDBG("norm ok");
+      bool fresh = false;
+      if (!plan[which].valid) { int rc = sparse_plan_from_current(which); if (rc != CH_OK) { status = 2; break; } d = sparse_dev(which); fresh = true; }
+      SPDBG("plan ready");
+      const bool damp = a.mode == MODE_DC && a.dv_max > 0.0 && !A.mos_hdev.empty();
+      double scale = 1.0;
+      bool failed = false;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        hipLaunchKernelGGL(sp_lu_solve_kernel, dim3(1), dim3(1024), 0, st, d);
+        if (damp) {
+          hipLaunchKernelGGL(sp_norms_kernel, dim3(1), dim3(1024), 0, st, a, d, 1);
+          int rc = sp_sync(); if (rc != CH_OK) return rc;
+          if (!h_flag[0] && h_red[1] > a.dv_max) scale = a.dv_max / h_red[1];
+        }
+        hipLaunchKernelGGL(sp_update_kernel, dim3(1), dim3(1024), 0, st, a, d, scale);  // no-op when the factorisation failed
+        int rc = sp_sync(); if (rc != CH_OK) return rc;
+        n_launch += 2;
+        if (!h_flag[0]) break;
+        // a static pivot became zero: re-analyse once with the current values (KLU would re-pivot here too)
+        if (fresh || attempt == 1) { failed = true; break; }
+        rc = sparse_plan_from_current(which); if (rc != CH_OK) { failed = true; break; }
+        d = sparse_dev(which); fresh = true;
+      }
+      SPDBG("solved");
+      if (failed) { status = 2; break; }
+      ++iters;
+      if (h_flag[1]) { status = 2; break; }
+      if (a.mode == MODE_TRAN) {
+        const double dn = std::sqrt(h_red[2] / n);
+        if (it == 0) { if (dn <= a.newton_tol || (rate_prev < 0.9 && 2.0 * std::max(rate_prev, 0.02) * dn <= a.newton_tol)) { status = 0; break; } }
+        else { rate_new = dn_prev > 0 ? dn / dn_prev : 0.0; if (dn <= a.newton_tol) { status = 0; break; } }
+        dn_prev = dn;
+      }
+    }
+    if (a.mode == MODE_TRAN && status == 0) sp_rate = iters >= 2 ? std::min(1.0, std::max(rate_new, 1e-4)) : std::min(1.0, rate_prev * 1.5);
+    SPDBG("commit");
+    hipLaunchKernelGGL(sp_commit_kernel, dim3(1), dim3(1024), 0, st, a, d, (a.mode == MODE_TRAN) ? 0 : 1);
+    int rc = sp_sync(); if (rc != CH_OK) return rc;
+    n_launch += 1;
+    out.n_fail = status != 0; out.n_singular = status == 2; out.max_iters = iters; out.sum_iters = iters; out.sum_block_iters = iters; out.fnorm = fnorm;
+    const double nd_ = h_red[7];
+    if (a.mode == MODE_TRAN && nd_ > 0) { out.errk = a.ck * std::sqrt(h_red[4] / nd_); out.errkm1 = a.ckm1 * std::sqrt(h_red[5] / nd_); out.errkp1 = a.ckp1 * std::sqrt(h_red[6] / nd_); }
+    sp_status = status;
+    return CH_OK;
+  }
+  int sp_status = 0;
+
   // host_active: host copy of the per-block active mask given to the kernel (DC restart passes, ch_eval), or null
   int run_newton(const NewtonArgs& a, const unsigned char* host_active, Summary& out) {
+    if (path == 2) return run_sparse(a, out);
     hipStream_t st = ctx->stream;
     const int nblk = A.n_comp * S;
     // kernel duration is sampled with HIP events on 1 launch in 4 (the events cost host time on every step)
@@ -618,7 +795,8 @@ struct ch_circuit {
         if (rc != CH_OK) return rc;
       }
       if (stt) { stt->n_block_iters += sm.sum_block_iters; stt->nnonliniter += sm.sum_iters; stt->nf += sm.sum_iters; stt->njacs += sm.sum_iters; stt->nfactors += sm.sum_iters; stt->nsolve += sm.sum_iters; }
-      if (host_reduce) std::memcpy(bo.data(), h_out, nblk * sizeof(BlockOut)); else HIPCHK(hipMemcpy(bo.data(), d_out.p, nblk * sizeof(BlockOut), hipMemcpyDeviceToHost));
+      if (path == 2) { for (int b = 0; b < nblk; ++b) bo[b].status = sp_status; }
+      else if (host_reduce) std::memcpy(bo.data(), h_out, nblk * sizeof(BlockOut)); else HIPCHK(hipMemcpy(bo.data(), d_out.p, nblk * sizeof(BlockOut), hipMemcpyDeviceToHost));
       n_active = 0;
       for (int b = 0; b < nblk; ++b) if (active[b]) { if (bo[b].status == 0) active[b] = 0; else ++n_active; }
       if (n_active > 0 && stt) { stt->nrestarts++; stt->nnonlinconvfail++; }
@@ -902,7 +1080,8 @@ int ch_circuit_info(ch_circuit* c, ch_info* o) {
   const Analysis& A = c->A;
   o->n_nodes = c->n_nodes; o->n_branches = A.n_branch; o->n_mna = A.n_mna; o->n_unknowns = A.n_unk; o->n_known = (int)A.known.size() - 1;
   o->n_alias = A.n_alias; o->n_components = A.n_comp; o->max_component = A.max_nc; o->n_classes = (int)A.classes.size();
-  o->n_mos = (int)A.mos_hdev.size(); o->n_mos_classes = c->n_cls; o->path = 1; o->n_samples = c->S;
+  o->n_mos = (int)A.mos_hdev.size(); o->n_mos_classes = c->n_cls; o->path = c->path; o->n_samples = c->S;
+  o->nnz_jac = (int64_t)c->h_colidx.size(); o->nnz_lu = c->plan[1].valid ? c->plan[1].nnz_lu : (c->plan[0].valid ? c->plan[0].nnz_lu : 0);
   return CH_OK;
 }
 // maps for tests / host mirrors: MNA index -> unknown (or -1) for nodes 0..n_nodes and branches
@@ -1008,15 +1187,28 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
   Summary sm;
   rc = c->run_newton(a, act.data(), sm);
   if (rc != CH_OK) return rc;
-  std::vector<double> hA((size_t)nblk * ds * ds), hF((size_t)nblk * ds), hQ((size_t)nblk * ds);
-  (void)hipMemcpy(hA.data(), c->d_dumpA.p, hA.size() * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipMemcpy(hF.data(), c->d_dumpF.p, hF.size() * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipMemcpy(hQ.data(), c->d_dumpQ.p, hQ.size() * sizeof(double), hipMemcpyDeviceToHost);
   const int n = A.n_mna;
   std::vector<char> has(n, 0);
   if (J_out) std::fill(J_out, J_out + (size_t)n * n, 0.0);
   if (F_out) std::fill(F_out, F_out + n, 0.0);
   if (Q_out) std::fill(Q_out, Q_out + n, 0.0);
+  if (c->path == 2) {
+    const size_t nnz = c->h_colidx.size();
+    std::vector<double> av(nnz), fv(A.n_unk), qv(A.n_unk);
+    (void)hipMemcpy(av.data(), c->sp_Aval.p, nnz * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(fv.data(), c->sp_F.p, fv.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(qv.data(), c->sp_Q.p, qv.size() * sizeof(double), hipMemcpyDeviceToHost);
+    for (int u = 0; u < A.n_unk; ++u) {
+      const int ri = A.unk_mna[u]; has[ri] = 1;
+      if (F_out) F_out[ri] = fv[u];
+      if (Q_out) Q_out[ri] = qv[u];
+      if (J_out) for (int p = c->h_rowptr[u]; p < c->h_rowptr[u + 1]; ++p) J_out[(size_t)ri * n + A.unk_mna[c->h_colidx[p]]] = av[p];
+    }
+  } else {
+  std::vector<double> hA((size_t)nblk * ds * ds), hF((size_t)nblk * ds), hQ((size_t)nblk * ds);
+  (void)hipMemcpy(hA.data(), c->d_dumpA.p, hA.size() * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hF.data(), c->d_dumpF.p, hF.size() * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hQ.data(), c->d_dumpQ.p, hQ.size() * sizeof(double), hipMemcpyDeviceToHost);
   for (int k = 0; k < A.n_comp; ++k) {
     const int blk = k * S + sample, nc = A.comp_nc[k], uo = A.comp_uofs[k];
     for (int i = 0; i < nc; ++i) {
@@ -1026,6 +1218,7 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
       if (Q_out) Q_out[ri] = hQ[(size_t)blk * ds + i];
       if (J_out) for (int j = 0; j < nc; ++j) J_out[(size_t)ri * n + A.unk_mna[uo + j]] = hA[(size_t)blk * ds * ds + (size_t)i * nc + j];
     }
+  }
   }
   if (J_out) for (int i = 0; i < n; ++i) if (!has[i]) J_out[(size_t)i * n + i] = 1.0;
   return CH_OK;

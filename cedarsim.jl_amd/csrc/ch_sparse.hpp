@@ -1,0 +1,401 @@
+// ch_sparse.hpp — sparse path for Jacobian blocks that do not fit one CU's LDS (large coupled circuits).
+//
+// north_star: "KLU-ordered … sparse LU re-factor + triangular solve in HIP".  KLU's recipe is:
+// analyse once on the host (permute to a zero-free diagonal, fill-reducing ordering, symbolic
+// factorisation), then RE-factor numerically with the pivot sequence fixed.  Here:
+//   host  (once per circuit and analysis kind): maximum transversal on the numerically significant
+//          entries (zero-free diagonal for branch rows), minimum-degree ordering of the symmetrised
+//          pattern, row-wise symbolic factorisation with fill, dependency levels, and a flat
+//          "op list" per row: for every L entry (l_ik) the list of (destination, source) positions
+//          of the updates a_ij -= l_ik * u_kj;
+//   GPU   (every Newton iteration): device evaluation → stamps in HBM, CSR gather assembly of
+//          A = G + α0·C, C, F, Q (deterministic, no atomics), numeric re-factorisation + forward /
+//          backward substitution level by level inside ONE workgroup (one wavefront per row, lanes
+//          over the updates of an L entry, __syncthreads between levels), update and norms.
+// KLU is Gilbert-Peierls without supernodes; no dense supernode blocks ≥16x16
+// arise in the circuits tested, so MFMA is not used.  The reference itself never selects a sparse
+// solver; this path is checked against the oracle's dense LU and closed forms.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <set>
+#include <vector>
+
+#include "ch_analysis.hpp"
+#include "ch_kernels.hpp"
+
+namespace chip {
+
+struct SparsePlan {
+  int n = 0;
+  // CSR pattern of A in unknown space + gather lists
+  std::vector<int> rowptr, colidx;
+  std::vector<int> mat_gptr, mat_gsrc;  // per nnz: staging offsets (G slot; C slot = +16)
+  std::vector<int> vec_gptr, vec_gsrc;  // per row: staging offsets (F slot; Q slot = +4)
+  // LU structure in pivot space
+  std::vector<int> prow, pcol;          // pivot step k -> original row / column
+  std::vector<int> a2lu;                // per nnz of A: position in LU values
+  int nnz_lu = 0;
+  std::vector<int> diag_pos;            // per pivot row: position of u_kk
+  // rows grouped by level (factorisation and forward solve) and by reverse level (backward solve)
+  std::vector<int> lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows;
+  // per pivot row: its L entries in ascending k
+  std::vector<int> lrow_ptr;            // [n+1] into the L-entry arrays
+  std::vector<int> l_pos, l_k, l_upd_ptr;   // per L entry: position of l_ik, pivot row k, [e..e+1] into upd arrays
+  std::vector<int> upd_dst, upd_src;    // positions in LU values
+  // per pivot row: its U entries (excluding the diagonal): positions and pivot-space columns
+  std::vector<int> urow_ptr, u_pos, u_col;
+  bool valid = false;
+};
+
+// Maximum transversal (augmenting DFS) restricted to "usable" entries; returns row_of_col or empty on failure.
+inline bool max_transversal(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<char>& usable,
+                            std::vector<int>& row_of_col) {
+  std::vector<int> col_of_row(n, -1);
+  row_of_col.assign(n, -1);
+  // cheap assignment: prefer the diagonal
+  for (int i = 0; i < n; ++i) for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) if (usable[p] && colidx[p] == i && row_of_col[i] < 0) { row_of_col[i] = i; col_of_row[i] = i; }
+  std::vector<int> visited(n, -1), par_row(n, -1), stack_row, stack_p;
+  for (int r0 = 0; r0 < n; ++r0) {
+    if (col_of_row[r0] >= 0) continue;
+    // iterative DFS for an augmenting path from the unmatched row r0 (MC21-style)
+    stack_row.assign(1, r0); stack_p.assign(1, rowptr[r0]);
+    int found = -1;
+    while (!stack_row.empty() && found < 0) {
+      const int r = stack_row.back();
+      int& p = stack_p.back();
+      bool pushed = false;
+      while (p < rowptr[r + 1]) {
+        const int q = p++;
+        if (!usable[q]) continue;
+        const int c = colidx[q];
+        if (visited[c] == r0) continue;
+        visited[c] = r0; par_row[c] = r;
+        if (row_of_col[c] < 0) { found = c; break; }
+        stack_row.push_back(row_of_col[c]); stack_p.push_back(rowptr[row_of_col[c]]);
+        pushed = true;
+        break;
+      }
+      if (found < 0 && !pushed) { stack_row.pop_back(); stack_p.pop_back(); }
+    }
+    if (found < 0) return false;
+    for (int c = found;;) {  // flip the matching along the path back to r0
+      const int r = par_row[c], prev_c = col_of_row[r];
+      row_of_col[c] = r; col_of_row[r] = c;
+      if (r == r0) break;
+      c = prev_c;
+    }
+  }
+  return true;
+}
+
+// Build the plan.  aval: numeric values of A (same order as colidx) used to pick significant entries.
+inline int sparse_analyse(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& aval, SparsePlan& P) {
+  P.n = n; P.rowptr = rowptr; P.colidx = colidx;
+  const int nnz = (int)colidx.size();
+  // 1. zero-free diagonal on significant entries (|a| >= 1e-3 of the row maximum), fall back to any structural entry
+  std::vector<char> usable(nnz, 0);
+  for (int i = 0; i < n; ++i) {
+    double mx = 0; for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) mx = std::max(mx, std::fabs(aval[p]));
+    for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) usable[p] = (mx > 0 && std::fabs(aval[p]) >= 1e-3 * mx);
+  }
+  std::vector<int> row_of_col;
+  if (!max_transversal(n, rowptr, colidx, usable, row_of_col)) {
+    std::fill(usable.begin(), usable.end(), 1);
+    if (!max_transversal(n, rowptr, colidx, usable, row_of_col)) return CH_ERR_SINGULAR;
+  }
+  // B = Pr*A with B(c,:) = A(row_of_col[c],:)  → diagonal entry (c,c) present
+  // 2. minimum-degree ordering on the pattern of B + B^T
+  std::vector<std::set<int>> adj(n);
+  for (int c = 0; c < n; ++c) { const int r = row_of_col[c]; for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) { const int j = colidx[p]; if (j != c) { adj[c].insert(j); adj[j].insert(c); } } }
+  std::vector<int> order; order.reserve(n);
+  {
+    std::vector<char> gone(n, 0);
+    std::set<std::pair<int, int>> pq;
+    for (int v = 0; v < n; ++v) pq.insert({(int)adj[v].size(), v});
+    while (!pq.empty()) {
+      const int v = pq.begin()->second; pq.erase(pq.begin());
+      gone[v] = 1; order.push_back(v);
+      std::vector<int> nb(adj[v].begin(), adj[v].end());
+      for (int u : nb) { pq.erase({(int)adj[u].size(), u}); adj[u].erase(v); }
+      for (size_t i = 0; i < nb.size(); ++i) for (size_t j = i + 1; j < nb.size(); ++j) { adj[nb[i]].insert(nb[j]); adj[nb[j]].insert(nb[i]); }
+      for (int u : nb) pq.insert({(int)adj[u].size(), u});
+      adj[v].clear();
+    }
+  }
+  P.pcol = order;
+  P.prow.resize(n);
+  std::vector<int> pos_of_col(n);
+  for (int k = 0; k < n; ++k) { pos_of_col[order[k]] = k; P.prow[k] = row_of_col[order[k]]; }
+  // 3. symbolic row-wise factorisation in pivot space
+  std::vector<std::vector<int>> rowpat(n);  // sorted pivot-space columns of row k of L+U
+  for (int k = 0; k < n; ++k) {
+    std::set<int> pat;
+    const int r = P.prow[k];
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) pat.insert(pos_of_col[colidx[p]]);
+    pat.insert(k);
+    for (auto it = pat.begin(); it != pat.end() && *it < k; ++it) {
+      const int kk = *it;
+      for (int j : rowpat[kk]) if (j > kk) pat.insert(j);
+    }
+    rowpat[k].assign(pat.begin(), pat.end());
+  }
+  std::vector<int> lu_ptr(n + 1, 0);
+  for (int k = 0; k < n; ++k) lu_ptr[k + 1] = lu_ptr[k] + (int)rowpat[k].size();
+  P.nnz_lu = lu_ptr[n];
+  auto find_pos = [&](int row, int col) { const auto& rp = rowpat[row]; return lu_ptr[row] + (int)(std::lower_bound(rp.begin(), rp.end(), col) - rp.begin()); };
+  P.a2lu.assign(nnz, -1);
+  for (int k = 0; k < n; ++k) { const int r = P.prow[k]; for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) P.a2lu[p] = find_pos(k, pos_of_col[colidx[p]]); }
+  P.diag_pos.resize(n);
+  for (int k = 0; k < n; ++k) P.diag_pos[k] = find_pos(k, k);
+  // 4. op lists and levels
+  std::vector<int> level(n, 0), ulevel(n, 0);
+  P.lrow_ptr.assign(n + 1, 0); P.urow_ptr.assign(n + 1, 0);
+  P.l_pos.clear(); P.l_k.clear(); P.l_upd_ptr.clear(); P.upd_dst.clear(); P.upd_src.clear(); P.u_pos.clear(); P.u_col.clear();
+  P.l_upd_ptr.push_back(0);
+  for (int k = 0; k < n; ++k) {
+    int lv = 0;
+    for (int j : rowpat[k]) {
+      if (j < k) {
+        lv = std::max(lv, level[j] + 1);
+        P.l_pos.push_back(find_pos(k, j)); P.l_k.push_back(j);
+        for (int c : rowpat[j]) if (c > j) { P.upd_dst.push_back(find_pos(k, c)); P.upd_src.push_back(find_pos(j, c)); }
+        P.l_upd_ptr.push_back((int)P.upd_dst.size());
+      } else if (j > k) { P.u_pos.push_back(find_pos(k, j)); P.u_col.push_back(j); }
+    }
+    level[k] = lv;
+    P.lrow_ptr[k + 1] = (int)P.l_pos.size();
+    P.urow_ptr[k + 1] = (int)P.u_pos.size();
+  }
+  for (int k = n - 1; k >= 0; --k) { int lv = 0; for (int j : rowpat[k]) if (j > k) lv = std::max(lv, ulevel[j] + 1); ulevel[k] = lv; }
+  auto group = [&](const std::vector<int>& lev, std::vector<int>& ptr, std::vector<int>& rows) {
+    int nl = 0; for (int v : lev) nl = std::max(nl, v + 1);
+    ptr.assign(nl + 1, 0);
+    for (int v : lev) ptr[v + 1]++;
+    for (int i = 0; i < nl; ++i) ptr[i + 1] += ptr[i];
+    rows.resize(n);
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (int k = 0; k < n; ++k) rows[fill[lev[k]]++] = k;
+  };
+  group(level, P.lvl_ptr, P.lvl_rows);
+  group(ulevel, P.ulvl_ptr, P.ulvl_rows);
+  P.valid = true;
+  return CH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SparseDev {
+  // structure
+  const int* rowptr; const int* colidx; const int* mat_gptr; const int* mat_gsrc; const int* vec_gptr; const int* vec_gsrc;
+  const int* prow; const int* pcol; const int* a2lu; const int* diag_pos;
+  const int* lvl_ptr; const int* lvl_rows; const int* ulvl_ptr; const int* ulvl_rows;
+  const int* lrow_ptr; const int* l_pos; const int* l_k; const int* l_upd_ptr; const int* upd_dst; const int* upd_src;
+  const int* urow_ptr; const int* u_pos; const int* u_col;
+  int n, nnz, nnz_lu, n_lvl, n_ulvl, n_dev;
+  // work arrays
+  double* stage; double* Aval; double* Cval; double* LUv; double* F; double* Q; double* rhs; double* y; double* dx;
+  double* xcur; double* xpred; double* hq; double* w; double* qn;
+  double* red;   // mapped host memory: [8] reductions
+  int* flag;     // mapped host memory: [2] {singular, bad}
+  int* dflag;    // device memory: [1] singular flag of the last factorisation (read by the update kernel)
+};
+
+// predictor / history term / Newton weights
+__global__ void sp_predict_kernel(const NewtonArgs a, const SparseDev d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n) return;
+  const double x0 = a.X[(long)a.hist_slot[0] * a.slot_stride + i];
+  double p = x0, h = 0.0;
+  if (a.mode == MODE_TRAN) {
+    p = 0.0;
+    for (int j = 0; j < a.npred; ++j) p += a.wpred[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + i];
+    for (int j = 1; j <= a.k; ++j) h += a.alpha[j] * a.Qh[(long)a.hist_slot[j - 1] * a.slot_stride + i];
+  }
+  d.xpred[i] = p; d.xcur[i] = p; d.hq[i] = h; d.qn[i] = 0.0;
+  d.w[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
+}
+
+// one thread per device instance: stamps to HBM
+__global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const SparseDev d) {
+  const int dev = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dev >= d.n_dev) return;
+  const double* kvl = a.inline_vals ? nullptr : a.kv;
+  const int kind = a.dkind[dev];
+  const int* tm = a.dterm + 4 * dev;
+  double v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = tm[k];
+    if (t >= 0) v[k] = d.xcur[t];
+    else if (a.inline_vals) { double kvv = 0.0; for (int q = 0; q < KV_INLINE; ++q) if (q == -t - 1) kvv = a.vals_inline[q]; v[k] = kvv; }
+    else v[k] = kvl[-t - 1];
+  }
+  const int hd = a.dhdev[dev];
+  const long pi = (long)hd * a.Spar;
+  const double m = a.dmult[pi];
+  double* st = d.stage + (size_t)dev * 40;
+  auto srcval = [&](int si) { if (a.inline_vals) { double r = 0.0; for (int q = 0; q < KV_INLINE; ++q) if (q == a.nk + si) r = a.vals_inline[q]; return r; } return a.srcv[si]; };
+  if (kind == K_MOS) {
+    const B4Col P = b4_col(a.mosp, (long)a.dcls[dev] * a.Smos);
+    double o[40];
+    b4_device(P, v[0], v[1], v[2], v[3], a.gmin_s[0], o);
+    for (int j = 0; j < 40; ++j) st[j] = m * o[j];
+    return;
+  }
+  for (int j = 0; j < 40; ++j) st[j] = 0.0;
+  switch (kind) {
+    case K_R: { const double g = m / a.dpar[pi], i = g * (v[0] - v[1]); st[0] = i; st[1] = -i; st[8] = g; st[9] = -g; st[12] = -g; st[13] = g; } break;
+    case K_C: { const double c = m * a.dpar[pi], q = c * (v[0] - v[1]); st[4] = q; st[5] = -q; st[24] = c; st[25] = -c; st[28] = -c; st[29] = c; } break;
+    case K_I: { const double i = m * srcval(a.dsrc[dev]); st[0] = i; st[1] = -i; } break;
+    case K_V: case K_L: case K_VCVS_A: {
+      const double ib = v[2], src = kind == K_V ? srcval(a.dsrc[dev]) : 0.0, l = kind == K_L ? a.dpar[pi] : 0.0;
+      st[0] = m * ib; st[1] = -m * ib; st[2] = v[0] - v[1] - src; st[6] = -l * ib;
+      st[8 + 2] = m; st[8 + 6] = -m; st[8 + 8] = 1.0; st[8 + 9] = -1.0; st[24 + 10] = -l;
+    } break;
+    case K_VCVS_B: { const double g = a.dpar[pi]; st[0] = -g * (v[1] - v[2]); st[8 + 1] = -g; st[8 + 2] = g; } break;
+    case K_VCCS: { const double g = m * a.dpar[pi], i = g * (v[2] - v[3]); st[0] = i; st[1] = -i; st[8 + 2] = g; st[8 + 3] = -g; st[8 + 6] = -g; st[8 + 7] = g; } break;
+  }
+}
+
+// CSR gather assembly: one thread per nnz and per row
+__global__ void sp_assemble_kernel(const NewtonArgs a, const SparseDev d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
+  if (i < d.nnz) {
+    double g = 0.0, c = 0.0;
+    for (int p = d.mat_gptr[i]; p < d.mat_gptr[i + 1]; ++p) { const int o = d.mat_gsrc[p]; g += d.stage[o]; c += d.stage[o + 16]; }
+    d.Aval[i] = g + alpha0 * c; d.Cval[i] = c;
+  }
+  if (i < d.n) {
+    double f = 0.0, q = 0.0;
+    for (int p = d.vec_gptr[i]; p < d.vec_gptr[i + 1]; ++p) { const int o = d.vec_gsrc[p]; f += d.stage[o]; q += d.stage[o + 4]; }
+    if (a.gshunt != 0.0 && !(a.dmask[i] & 2)) f += a.gshunt * d.xcur[i];
+    d.Q[i] = q;
+    const double F = f + alpha0 * q + d.hq[i];
+    d.F[i] = F; d.rhs[i] = -F;
+  }
+}
+__global__ void sp_diag_shunt_kernel(const NewtonArgs a, const SparseDev d) {  // gmin stepping: + gshunt on node diagonals
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n || (a.dmask[i] & 2)) return;
+  for (int p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) if (d.colidx[p] == i) d.Aval[p] += a.gshunt;
+}
+
+// Numeric re-factorisation + both triangular solves inside ONE workgroup.
+__global__ __launch_bounds__(1024) void sp_lu_solve_kernel(const SparseDev d) {
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  for (int i = tid; i < d.nnz_lu; i += nthr) d.LUv[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < d.nnz; i += nthr) d.LUv[d.a2lu[i]] = d.Aval[i];
+  __shared__ int s_sing;
+  if (tid == 0) s_sing = 0;
+  __syncthreads();
+  // factorisation: rows of a level are independent; one wavefront per row, lanes over the updates of one L entry
+  for (int lv = 0; lv < d.n_lvl; ++lv) {
+    for (int r = d.lvl_ptr[lv] + wave; r < d.lvl_ptr[lv + 1]; r += nwave) {
+      const int k = d.lvl_rows[r];
+      for (int e = d.lrow_ptr[k]; e < d.lrow_ptr[k + 1]; ++e) {
+        const double ukk = d.LUv[d.diag_pos[d.l_k[e]]];
+        const double l = d.LUv[d.l_pos[e]] / ukk;
+        for (int p = d.l_upd_ptr[e] + lane; p < d.l_upd_ptr[e + 1]; p += 64) d.LUv[d.upd_dst[p]] -= l * d.LUv[d.upd_src[p]];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) d.LUv[d.l_pos[e]] = l;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      const double ukk = d.LUv[d.diag_pos[k]];
+      if (lane == 0 && (!(fabs(ukk) > 0.0) || !(fabs(ukk) < 1e300))) s_sing = 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (tid == 0) { d.flag[0] = s_sing; d.dflag[0] = s_sing; }
+  if (s_sing) return;
+  // forward: y_k = b(prow[k]) - sum_j l_kj y_j   (rows of a level independent)
+  for (int lv = 0; lv < d.n_lvl; ++lv) {
+    for (int r = d.lvl_ptr[lv] + tid; r < d.lvl_ptr[lv + 1]; r += nthr) {
+      const int k = d.lvl_rows[r];
+      double s = d.rhs[d.prow[k]];
+      for (int e = d.lrow_ptr[k]; e < d.lrow_ptr[k + 1]; ++e) s -= d.LUv[d.l_pos[e]] * d.y[d.l_k[e]];
+      d.y[k] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // backward: z_k = (y_k - sum_{j>k} u_kj z_j) / u_kk ; dx(pcol[k]) = z_k
+  for (int lv = 0; lv < d.n_ulvl; ++lv) {
+    for (int r = d.ulvl_ptr[lv] + tid; r < d.ulvl_ptr[lv + 1]; r += nthr) {
+      const int k = d.ulvl_rows[r];
+      double s = d.y[k];
+      for (int e = d.urow_ptr[k]; e < d.urow_ptr[k + 1]; ++e) s -= d.LUv[d.u_pos[e]] * d.dx[d.pcol[d.u_col[e]]];
+      d.dx[d.pcol[k]] = s / d.LUv[d.diag_pos[k]];
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// reductions: red[0]=max|F|, red[1]=max|dx| over node rows, red[2]=sum (dx*w)^2, red[3]=bad flag
+__global__ __launch_bounds__(1024) void sp_norms_kernel(const NewtonArgs a, const SparseDev d, int what) {
+  __shared__ double s0[1024], s1[1024], s2[1024];
+  const int t = threadIdx.x;
+  double m0 = 0, m1 = 0, m2 = 0;
+  for (int i = t; i < d.n; i += 1024) {
+    if (what == 0) m0 = fmax(m0, fabs(d.F[i]));
+    else { if (!(a.dmask[i] & 2)) m1 = fmax(m1, fabs(d.dx[i])); }
+  }
+  s0[t] = m0; s1[t] = m1; s2[t] = m2;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (t < o) { s0[t] = fmax(s0[t], s0[t + o]); s1[t] = fmax(s1[t], s1[t + o]); } __syncthreads(); }
+  if (t == 0) { if (what == 0) d.red[0] = s0[0]; else d.red[1] = s1[0]; }
+}
+
+// x += scale*dx ; qn = Q + C*(scale*dx) ; e2 = sum (scale*dx*w)^2 ; bad flag
+__global__ __launch_bounds__(1024) void sp_update_kernel(const NewtonArgs a, const SparseDev d, double scale) {
+  __shared__ double s2[1024]; __shared__ int sbad;
+  const int t = threadIdx.x;
+  if (d.dflag[0]) return;  // factorisation failed: leave the iterate untouched (the host re-analyses and retries)
+  if (t == 0) sbad = 0;
+  __syncthreads();
+  double e2 = 0;
+  for (int i = t; i < d.n; i += 1024) {
+    const double dxi = scale * d.dx[i];
+    const double xn = d.xcur[i] + dxi;
+    if (!(xn == xn) || fabs(xn) > 1e300) sbad = 1;
+    const double tt = dxi * d.w[i]; e2 += tt * tt;
+    if (a.mode == MODE_TRAN) { double q = d.Q[i]; for (int p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) q += d.Cval[p] * scale * d.dx[d.colidx[p]]; d.qn[i] = q; }
+  }
+  s2[t] = e2;
+  __syncthreads();
+  for (int i = t; i < d.n; i += 1024) d.xcur[i] += scale * d.dx[i];
+  for (int o = 512; o > 0; o >>= 1) { if (t < o) s2[t] += s2[t + o]; __syncthreads(); }
+  if (t == 0) { d.red[2] = s2[0]; d.flag[1] = sbad; }
+}
+
+// commit candidate state, observables, local-error sums: red[4..7] = e2k, e2km1, e2kp1, ndiff
+__global__ __launch_bounds__(1024) void sp_commit_kernel(const NewtonArgs a, const SparseDev d, int use_q_of_eval) {
+  __shared__ double s0[1024], s1[1024], s2[1024], s3[1024];
+  const int t = threadIdx.x;
+  double e2k = 0, e2m = 0, e2p = 0, nd = 0;
+  for (int i = t; i < d.n; i += 1024) {
+    const double xn = d.xcur[i];
+    a.X[(long)a.cand_slot * a.slot_stride + i] = xn;
+    a.Qh[(long)a.cand_slot * a.slot_stride + i] = use_q_of_eval ? d.Q[i] : d.qn[i];
+    if (a.obs_row) { const int ob = a.unk_obs[i]; if (ob >= 0) a.obs_row[ob] = xn; }
+    if (a.mode == MODE_TRAN && (a.dmask[i] & 1)) {
+      const double x0 = a.X[(long)a.hist_slot[0] * a.slot_stride + i];
+      const double w = 1.0 / (a.reltol * fmax(fabs(x0), fabs(xn)) + a.abstol);
+      nd += 1.0;
+      double tt = (xn - d.xpred[i]) * w; e2k += tt * tt;
+      if (a.nkm1 > 0) { double p = 0.0; for (int j = 0; j < a.nkm1; ++j) p += a.wkm1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + i]; tt = (xn - p) * w; e2m += tt * tt; }
+      if (a.nkp1 > 0) { double p = 0.0; for (int j = 0; j < a.nkp1; ++j) p += a.wkp1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + i]; tt = (xn - p) * w; e2p += tt * tt; }
+    }
+  }
+  s0[t] = e2k; s1[t] = e2m; s2[t] = e2p; s3[t] = nd;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (t < o) { s0[t] += s0[t + o]; s1[t] += s1[t + o]; s2[t] += s2[t + o]; s3[t] += s3[t + o]; } __syncthreads(); }
+  if (t == 0) { d.red[4] = s0[0]; d.red[5] = s1[0]; d.red[6] = s2[0]; d.red[7] = s3[0]; }
+}
+
+}  // namespace chip

@@ -110,6 +110,48 @@ def dff_array(n_tiles=1, skew=None, observe="q", gmin=1e-15):
     return c
 
 
+def dff_chain(n_stages, gmin=1e-15):
+    """Shift register: Q of stage i drives D of stage i+1 (one COUPLED Jacobian block of 11*n unknowns).
+    Exercises the sparse path: the block does not fit one CU's LDS for n_stages >= 6."""
+    c = Circuit(gmin=gmin)
+    m = gf180_models()
+    mi = {"n": c.add_model(*m["nfet_06v0"]), "p": c.add_model(*m["pfet_06v0"])}
+    c.V("vvdd", "vdd", 0, dc=5.0)
+    c.V("vvss", "vss", 0, dc=0.0)
+    c.V("vnw", "vnw", "vdd", dc=0.0)
+    c.V("vpw", "vpw", "vss", dc=0.0)
+    c.V("vclkn", "clkn", 0, tran=PWL(CLKN_PWL))
+    c.V("vd", "d", 0, tran=PWL(D_PWL))
+    for t in range(n_stages):
+        pre = "x%d." % t
+
+        def nn(name):
+            if name in ("VDD", "VSS", "VNW", "VPW", "CLKN"):
+                return name.lower()
+            if name == "D":
+                return "d" if t == 0 else "x%d.q" % (t - 1)
+            return pre + name.lower()
+
+        for name, d, g, s, b, typ, w in DFF_FETS:
+            c.M(pre + "x_" + name, nn(d), nn(g), nn(s), nn(b), mi[typ], w, LN if typ == "n" else LP)
+        c.C(pre + "cq", pre + "q_tmp", 0, 1.7205e-13 / 8)
+        c.V(pre + "vq", nn("Q"), pre + "q_tmp", dc=0.0)
+        c.observe_node(nn("Q"))
+    return c
+
+
+def rc_ladder(n_sections, r=1e3, cap=1e-12, vstep=1.0, trise=1e-9):
+    """Uniform RC ladder driven by a ramped step: one coupled block of n_sections unknowns (sparse path)."""
+    c = Circuit()
+    c.V("vin", "n0", 0, tran=PWL([0.0, 0.0, trise, vstep, 1.0, vstep]))
+    for i in range(n_sections):
+        c.R("r%d" % i, "n%d" % i, "n%d" % (i + 1), r)
+        c.C("c%d" % i, "n%d" % (i + 1), 0, cap)
+    for i in (1, n_sections // 2, n_sections):
+        c.observe_node("n%d" % i)
+    return c
+
+
 INVERTER_NETLIST = """* Inverter test (test/inverter.jl:58-81)
 Xneg VSS D Q VSS nfet_06v0 W=3.6e-07 L=6e-07
 Xpos VDD D Q VDD pfet_06v0 W=4.95e-07 L=5e-07

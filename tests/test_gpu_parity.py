@@ -13,7 +13,7 @@ import pytest
 from cedarsim_jl_amd import (PULSE, SIN, Circuit, CircuitSweep, ProductSweep, dc, dc_opts, frange, parse_spice,
                              parse_spice_file, tran, tran_opts)
 from cedarsim_jl_amd import bsim4_params as B4
-from cedarsim_jl_amd.workloads import (DFF_CHECK_Q, DFF_CHECK_TIMES, dff_array, gf180_resolver, inverter)
+from cedarsim_jl_amd.workloads import (DFF_CHECK_Q, DFF_CHECK_TIMES, dff_array, dff_chain, gf180_resolver, inverter, rc_ladder)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -357,3 +357,35 @@ def test_full_size_array_properties(E):
     assert np.max(np.abs(q - np.array(DFF_CHECK_Q)[None, :])) < 1e-4
     assert np.max(np.abs(q - q[0:1])) < 1e-9  # tile equivalence
     assert st["n_block_iters"] >= 1024 * st["naccept"]
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse path: Jacobian blocks larger than one CU's LDS (level-scheduled LU re-factorisation)
+def test_sparse_path_rc_ladder_matches_oracle(E, O):
+    c = rc_ladder(300)
+    e, o = E(c), O(c)
+    sv = np.array([2e-9, 2e-8, 1e-7, 5e-7, 2e-6])
+    rc, t, v, xf, st = e.tran(0.0, 2e-6, tran_opts(abstol=1e-8, reltol=1e-6, saveat=sv))
+    info = e.info()
+    assert rc == 0 and info["path"] == 2 and info["n_unknowns"] == 300 and info["nnz_lu"] >= info["nnz_jac"] > 0
+    rco, to, vo, _, _ = o.tran(0.0, 2e-6, tran_opts(abstol=1e-8, reltol=1e-6, saveat=sv))
+    assert rco == 0 and np.max(np.abs(v[:, :, 0] - vo)) < 1e-4
+    # DC: every node sits at the source value; closed form
+    rc, x, status, st = e.dc(dc_opts(abstol=1e-12, tran_mode=True))
+    assert rc == 0 and np.nanmax(np.abs(x[0][:301] - 0.0)) < 1e-9
+
+
+def test_sparse_path_coupled_dff_chain_matches_oracle(E, O):
+    """Six flip-flops in a shift register: one coupled 66-unknown MOS block (does not fit the fused kernel)."""
+    c = dff_chain(6)
+    e, o = E(c), O(c)
+    info = e.info()
+    assert info["n_components"] == 1 and info["n_unknowns"] == 66
+    rc, xo, _ = o.dc(dc_opts(abstol=1e-13))
+    assert rc == 0
+    sv = np.array([0.4e-7, 0.9e-7, 1.5e-7, 2.5e-7])
+    rc, t, v, xf, st = e.tran(0.0, 2.5e-7, tran_opts(abstol=1e-7, reltol=1e-7, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo[None, :])))
+    assert rc == 0 and e.info()["path"] == 2
+    rco, to, vo, _, _ = o.tran(0.0, 2.5e-7, tran_opts(abstol=1e-7, reltol=1e-7, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo)))
+    assert rco == 0
+    assert np.max(np.abs(v[:, :, 0] - vo)) < 1e-4 * 5.0
