@@ -389,3 +389,57 @@ def test_sparse_path_coupled_dff_chain_matches_oracle(E, O):
     rco, to, vo, _, _ = o.tran(0.0, 2.5e-7, tran_opts(abstol=1e-7, reltol=1e-7, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo)))
     assert rco == 0
     assert np.max(np.abs(v[:, :, 0] - vo)) < 1e-4 * 5.0
+
+
+# ------------------------------------------------------------------------------------------------
+# config 2 of BASELINE.json: device evaluation + Jacobian assembly on the GPU, sparse LU on the host
+def test_config2_gpu_assembly_with_host_sparse_lu(E, O):
+    """benchmarks/gf180_dff: `prob.f.jac` from the GPU (ch_eval), Newton + LU on the host (SuperLU via
+    scipy, standing in for KLU): converges to the same DC operating point as the oracle."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    c = dff_array(1)
+    e, o = E(c), O(c)
+    nu, nk, bu = e.maps()
+    rc, xo, _ = o.dc(dc_opts(abstol=1e-14))
+    x = canon(c, xo + 0.02 * np.random.default_rng(5).standard_normal(xo.shape), nu)
+    for n in range(1, c.n_nodes + 1):
+        if nu[n] < 0:
+            x[n - 1] = xo[n - 1]
+    rows = sorted({int(u): n - 1 for n, u in enumerate(nu) if n > 0 and u >= 0}.values())
+    for it in range(50):
+        F, Q, J = e.eval(x, t=0.0, alpha0=0.0, mode=0)
+        if np.max(np.abs(F[rows])) < 1e-13:
+            break
+        lu = spla.splu(sp.csc_matrix(J))  # eliminated rows/cols come back as identity
+        dx = lu.solve(-F)
+        dx *= min(1.0, 1.0 / max(1e-30, np.max(np.abs(dx))))
+        x = canon(c, x + dx, nu)
+    assert it < 49
+    # net11 floats between two OFF transistors (set by fA leakage): compare the driven nodes directly and
+    # check the ORACLE's KCL residual at the converged point for all of them
+    ok = [n - 1 for n in range(1, c.n_nodes + 1) if c.node_names[n] not in ("net11", "net4")]
+    assert np.allclose(x[ok], xo[ok], rtol=1e-6, atol=1e-8)
+    Fo, _, _ = o.eval(x, t=0.0, alpha0=0.0, mode=0)
+    _, Fr, _ = reduce_rows(c, nu, Fo)
+    assert np.max(np.abs(Fr)) < 1e-12
+
+
+def test_monte_carlo_1024_samples_lockstep_gate(E):
+    """Config 4 shape on one GPU: 1024 process-variation samples in ONE batched transient; every
+    sample must satisfy the reference's logic gate (test/gf180_dff.jl:29-33)."""
+    c = dff_array(1)
+    slots, base = [], []
+    for m in ("nfet_06v0", "pfet_06v0"):
+        for p in ("vth0", "u0", "toxe"):
+            slots.append(c.slot(m, p))
+            base.append(c.models[c.model_names.index(m)][B4.PARAM_INDEX[p]])
+    S = 1024
+    vals = np.array(base)[:, None] * (1.0 + 0.03 * np.random.default_rng(2024).standard_normal((len(slots), S)))
+    e = E(c)
+    e.set_samples(S)
+    e.set_params(slots, vals)
+    rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14), saveat=np.array(DFF_CHECK_TIMES)))
+    assert rc == 0 and v.shape == (1, 5, S)
+    assert np.max(np.abs(v[0] - np.array(DFF_CHECK_Q)[:, None])) < 1e-3
+    assert st["n_block_iters"] >= S * st["naccept"]
