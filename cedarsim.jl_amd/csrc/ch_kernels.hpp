@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
         for (int base = tid; base < n; base += nthr * 8) {
           int v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; v[u] = i < n ? src[i] : 0; }
+          for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; v[u] = src[i < n ? i : n - 1]; }  // clamped: branch-free, all 8 loads in flight
 #pragma unroll
           for (int u = 0; u < 8; ++u) { const int i = base + u * nthr; if (i < n) mptr[i] = v[u]; }
         }
@@ -359,12 +359,13 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       const int total = nmc * B4I_COUNT;
       const long scol = a.Smos > 1 ? s : 0;
       constexpr int PB = 18;  // 8 DFF classes x 137 doubles / 64 lanes = 17.1: one batch of loads in flight
-      for (int base = tid; base < total; base += nthr * PB) {
+      if (total > 0) for (int base = tid; base < total; base += nthr * PB) {
         double v[PB];
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
-          const int e = base + u * nthr;
-          if (e < total) { const int j = e / B4I_COUNT, i = e - j * B4I_COUNT; v[u] = a.mosp[((long)mcl[j] * a.Smos + scol) * (long)B4I_COUNT + i]; } else v[u] = 0.0;
+          const int e0 = base + u * nthr, e = e0 < total ? e0 : total - 1;  // clamped: branch-free loads
+          const int j = e / B4I_COUNT, i = e - j * B4I_COUNT;
+          v[u] = a.mosp[((long)mcl[j] * a.Smos + scol) * (long)B4I_COUNT + i];
         }
 #pragma unroll
         for (int u = 0; u < PB; ++u) { const int e = base + u * nthr; if (e < total) pl[e] = v[u]; }
@@ -376,14 +377,14 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       if (a.mode == MODE_TRAN) {
         double xv[7], qv[5];  // all history loads are issued before any is used
 #pragma unroll
-        for (int j = 0; j < 7; ++j) xv[j] = j < a.npred ? a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i] : 0.0;
+        for (int j = 0; j < 7; ++j) xv[j] = a.X[(long)a.hist_slot[j < a.npred ? j : 0] * a.slot_stride + sofs + i];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) qv[j] = j < a.k ? a.Qh[(long)a.hist_slot[j] * a.slot_stride + sofs + i] : 0.0;
+        for (int j = 0; j < 5; ++j) qv[j] = a.Qh[(long)a.hist_slot[j < a.k ? j : 0] * a.slot_stride + sofs + i];
         p = 0.0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) p += a.wpred[j + 1] * xv[j];
+        for (int j = 0; j < 7; ++j) p += (j < a.npred ? a.wpred[j + 1] : 0.0) * xv[j];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) h += a.alpha[j + 1] * qv[j];
+        for (int j = 0; j < 5; ++j) h += (j < a.k ? a.alpha[j + 1] : 0.0) * qv[j];
       }
       xp[i] = p; xl[i] = p; hq[i] = h; qn[i] = 0.0;
       wv[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
