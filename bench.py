@@ -36,28 +36,48 @@ def algorithmic_bytes_per_block_iteration(nc, n_mos):
     return n_mos * 400 + n_mos * 288 + 8 * (nnz + nc) + 8 * (nnz + 2 * nnz) + 8 * (2 * nnz + 4 * nc)
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """Oracle ("port") timed on ONE host core on a bounded sample: one of the 1024 decoupled tiles,
-    full transient, repeated; converted to array-level iterations/s by dividing by the tile count."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _oracle_worker(args):
+    """One host thread: full transients of one decoupled DFF tile until the deadline (ctypes releases the GIL)."""
+    deadline, max_reps = args
     from oracle_binding import Oracle
     from cedarsim_jl_amd import dc_opts, tran_opts
     from cedarsim_jl_amd.workloads import DFF_TSPAN, dff_array
     o = Oracle(dff_array(1))
-    iters, reps, t0 = 0, 0, time.perf_counter()
+    iters = reps = 0
     while True:
         rc, t, v, xf, st = o.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=TOL, reltol=TOL, dc=dc_opts(abstol=1e-14)))
         assert rc == 0
         iters += st["nnonliniter"]
         reps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or reps >= 200:
+        if time.perf_counter() > deadline or reps >= max_reps:
             break
-    tile_rate = iters / el
-    return {"value": tile_rate / N_TILES, "unit": "newton_iters/s (1024-DFF array equivalent)", "cores": 1, "kind": "port",
-            "sample": "%d full transients of 1 of the %d decoupled DFF tiles (dense-LU MNA oracle, n=25), %.1f s; "
-                      "tile rate %.0f iters/s divided by %d" % (reps, N_TILES, el, tile_rate, N_TILES),
-            "seconds_per_tile_transient": el / reps}
+    return iters, reps
+
+
+def cpu_baseline(seconds_single=5.0, seconds_multi=10.0):
+    """Oracle ("port") timed on the host cores on a bounded sample: full transients of single decoupled tiles
+    (1 of the 1024), first on one core, then one tile per thread on every core this process may use;
+    converted to array-level iterations/s by dividing the tile rate by the tile count."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    t0 = time.perf_counter()
+    it1, reps1 = _oracle_worker((t0 + seconds_single, 200))
+    el1 = time.perf_counter() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(_oracle_worker, [(t0 + seconds_multi, 400)] * cores))
+    elm = time.perf_counter() - t0
+    itm, repsm = sum(r[0] for r in res), sum(r[1] for r in res)
+    tile_rate_1, tile_rate_m = it1 / el1, itm / elm
+    return {"value": tile_rate_m / N_TILES, "unit": "newton_iters/s (1024-DFF array equivalent)", "cores": cores, "kind": "port",
+            "sample": "%d full transients of single decoupled DFF tiles (1 of the %d; dense-LU MNA oracle, n=25) on %d threads, "
+                      "%.1f s; tile rate %.0f iters/s divided by %d" % (repsm, N_TILES, cores, elm, tile_rate_m, N_TILES),
+            "single_core_value": tile_rate_1 / N_TILES, "seconds_per_tile_transient_single_core": el1 / reps1}
 
 
 def main():
@@ -123,7 +143,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     iters = block_iters = launches = 0
-    dev_s = 0.0
+    dev_s = dc_s = 0.0
     naccept = nreject = 0
     q = None
     for _ in range(args.steps):
@@ -132,6 +152,7 @@ def main():
         block_iters += st["n_block_iters"]
         launches += st["n_kernel_launches"]
         dev_s += st["device_seconds"]
+        dc_s += st["dc_seconds"]
         naccept += st["naccept"]
         nreject += st["nreject"]
     barrier()
@@ -158,13 +179,19 @@ def main():
         avg_launch = dev_s / max(1, launches)
         bytes_per_launch = bpi * block_iters / max(1, launches)
         achieved = bytes_per_launch / avg_launch / 1e9 if avg_launch > 0 else 0.0
-        traffic = None
+        traffic = flops = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                flops = pj.get("fp64_flop_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
+        try:
+            triad, fp64_peak = ctx.triad_gbps(), ctx.fp64_tflops()
+        except RuntimeError:
+            triad = fp64_peak = None
         line = {
             "metric": "newton_iters_per_sec", "value": tot_iters / max_el, "unit": "newton_iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_el / max(1, args.steps),
@@ -173,6 +200,7 @@ def main():
                        "tiles": args.tiles, "mosfets": args.tiles * MOS_PER_TILE, "unknowns": info["n_unknowns"],
                        "blocks": info["n_components"], "block_size": nc, "device_cards": "substitute BSIM4 cards (GF180MCUPDK unavailable)",
                        "wall_seconds_per_transient": max_el / max(1, args.steps),
+                       "dc_seconds_per_transient": dc_s / max(1, args.steps),
                        "tile_newton_iters_per_sec": tot_iters * args.tiles / max_el,
                        "accepted_steps": naccept // max(1, args.steps), "rejected_steps": nreject // max(1, args.steps),
                        "reference_gate_q": all_q[0], "reference_gate_ok": gate_ok,
@@ -181,6 +209,9 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_block_iteration": bpi, "block_iterations_per_launch": block_iters / max(1, launches),
                          "avg_launch_us": 1e6 * avg_launch, "launches": launches,
+                         "peak_measured_triad": triad, "frac_of_measured_triad": (achieved / triad) if triad else None,
+                         "fp64_tflops_achieved": (flops / avg_launch / 1e12) if (flops and avg_launch > 0) else None,
+                         "fp64_vector_peak_tflops_measured": fp64_peak,
                          "note": "stamps and the block Jacobian stay in LDS, so HBM is not the limiter; the kernel is "
                                  "fp64-VALU/latency bound (see DESIGN.md)"},
         }

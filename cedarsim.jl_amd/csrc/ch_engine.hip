@@ -238,6 +238,7 @@ struct ch_circuit {
   void set_err(const std::string& s) { ctx->err = s; }
 
   ~ch_circuit() {
+    if (g_arena == &arena) g_arena = nullptr;
     if (h_sum) (void)hipHostFree(h_sum);
     if (h_out) (void)hipHostFree(h_out);
     if (h_red) (void)hipHostFree(h_red);
@@ -446,9 +447,7 @@ struct ch_circuit {
     { std::vector<double> ones((size_t)A.n_comp * S, 1.0); HIPCHK(d_rate.upload(ones, st)); }
     host_reduce = (size_t)A.n_comp * S <= 4096 && std::getenv("CEDARHIP_DEVICE_REDUCE") == nullptr;
     if (host_reduce && h_out_n < (size_t)A.n_comp * S) {
-      if (h_out) (void)hipHostFree(h_out);
-    if (h_red) (void)hipHostFree(h_red);
-    if (h_flag) (void)hipHostFree(h_flag);
+      if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; h_out_n = 0; }
       HIPCHK(hipHostMalloc((void**)&h_out, (size_t)A.n_comp * S * sizeof(BlockOut), hipHostMallocMapped));
       h_out_n = (size_t)A.n_comp * S;
     }
@@ -1065,7 +1064,21 @@ ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
   c->slot_val.assign(c->slot_kind.size(), {});
   std::vector<char> protect(c->dev.size(), 0), swept(c->src.size(), 0);
   for (size_t o = 0; o < c->obs_kind.size(); ++o) if (c->obs_kind[o] == 1) { if (c->obs_index[o] < 0 || c->obs_index[o] >= (int)c->dev.size()) return bad("observable device index out of range"); protect[c->obs_index[o]] = 1; }
-  for (size_t i = 0; i < c->slot_kind.size(); ++i) if (c->slot_kind[i] == CH_SLOT_SRC_DC || c->slot_kind[i] == CH_SLOT_SRC_PAR) swept[c->slot_a[i]] = 1;
+  for (size_t i = 0; i < c->slot_kind.size(); ++i) {
+    const int k = c->slot_kind[i], sa = c->slot_a[i], sb = c->slot_b[i];
+    bool ok = true;
+    switch (k) {
+      case CH_SLOT_DEV_PAR: ok = sa >= 0 && sa < (int)c->dev.size() && sb >= 0 && sb < CH_DEV_NPAR; break;
+      case CH_SLOT_DEV_MULT: ok = sa >= 0 && sa < (int)c->dev.size(); break;
+      case CH_SLOT_MODEL_PAR: ok = sa >= 0 && sa < (int)c->model.size() && sb >= 0 && sb < CH_B4_NPAR; break;
+      case CH_SLOT_SRC_DC: ok = sa >= 0 && sa < (int)c->src.size(); break;
+      case CH_SLOT_SRC_PAR: ok = sa >= 0 && sa < (int)c->src.size() && sb >= 0 && sb < CH_SRC_NPAR; break;
+      case CH_SLOT_TEMP: case CH_SLOT_GMIN: break;
+      default: ok = false;
+    }
+    if (!ok) return bad("parameter slot refers to a device, model, source or field that does not exist");
+    if (k == CH_SLOT_SRC_DC || k == CH_SLOT_SRC_PAR) swept[sa] = 1;
+  }
   int rc = analyse(c->n_nodes, c->dev, c->src, protect, swept, c->A);
   if (rc != CH_OK) { ctx->err = c->A.err; delete c; return nullptr; }
   rc = c->upload_structure();
@@ -1267,6 +1280,54 @@ int32_t ch_bsim4_param_ignored(const char* name) {
   if (!name) return 0;
   for (int i = 0; k_b4_ignored[i]; ++i) if (std::strcmp(k_b4_ignored[i], name) == 0) return 1;
   return 0;
+}
+int ch_bench_triad(ch_ctx* ctx, int64_t n, int32_t iters, double* gbps_out) {
+  if (!ctx || n < 1024 || iters < 1 || !gbps_out) return CH_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  double *a = nullptr, *b = nullptr, *c = nullptr;
+  const size_t bytes = (size_t)n * sizeof(double);
+  if (hipMalloc((void**)&a, bytes) != hipSuccess || hipMalloc((void**)&b, bytes) != hipSuccess || hipMalloc((void**)&c, bytes) != hipSuccess) {
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); ctx->err = "triad: out of device memory"; return CH_ERR_DEVICE;
+  }
+  (void)hipMemsetAsync(b, 0, bytes, ctx->stream); (void)hipMemsetAsync(c, 0, bytes, ctx->stream);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int threads = 256; const long n2 = n / 2;
+  const int blocks = (int)std::min<long>((n2 + threads - 1) / threads, 256L * 32);
+  double best = 0;
+  for (int it = 0; it <= iters; ++it) {
+    (void)hipEventRecord(e0, ctx->stream);
+    hipLaunchKernelGGL(triad_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, (double2*)a, (const double2*)b, (const double2*)c, 3.0, n2);
+    (void)hipEventRecord(e1, ctx->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) { ctx->err = "triad kernel failed"; break; }
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (it > 0 && ms > 0) best = std::max(best, 3.0 * (double)(n2 * 2) * sizeof(double) / (ms * 1e-3) / 1e9);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+  *gbps_out = best;
+  return best > 0 ? CH_OK : CH_ERR_DEVICE;
+}
+int ch_bench_fp64(ch_ctx* ctx, int32_t iters, double* tflops_out) {
+  if (!ctx || iters < 1 || !tflops_out) return CH_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return CH_ERR_DEVICE;
+  const int blocks = prop.multiProcessorCount * 8, threads = 256, n_outer = 2000;  // 8 waves per SIMD
+  double* out = nullptr;
+  if (hipMalloc((void**)&out, (size_t)blocks * threads * sizeof(double)) != hipSuccess) return CH_ERR_DEVICE;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  double best = 0;
+  for (int it = 0; it <= iters; ++it) {
+    (void)hipEventRecord(e0, ctx->stream);
+    hipLaunchKernelGGL(fp64_peak_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, out, n_outer, 0.999999, 1e-6);
+    (void)hipEventRecord(e1, ctx->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) { ctx->err = "fp64 peak kernel failed"; break; }
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * 16 * 8 * (double)n_outer * blocks * threads;
+    if (it > 0 && ms > 0) best = std::max(best, flop / (ms * 1e-3) / 1e12);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+  *tflops_out = best;
+  return best > 0 ? CH_OK : CH_ERR_DEVICE;
 }
 const char* ch_version(void) { return "cedarhip 0.1 (gfx950; fused block Newton)"; }
 

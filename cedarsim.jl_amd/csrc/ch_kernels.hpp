@@ -678,4 +678,36 @@ __global__ __launch_bounds__(64) void mos_eval_quad_kernel(const double* mosp, l
   b4_device_quad(P, v[4 * i + 0], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], gmin, sub, 1.0, out + (long)i * 40);
 }
 
+// fp64 FMA peak (measurement utility, ch_bench_fp64): 16 independent chains per lane
+__global__ __launch_bounds__(256) void fp64_peak_kernel(double* out, int n_outer, double a, double b) {
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = 1.0 + 1e-3 * (threadIdx.x + i);
+  for (int it = 0; it < n_outer; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = __builtin_fma(x[i], a, b);
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += x[i];
+  if (s == 123.456) out[blockIdx.x * blockDim.x + threadIdx.x] = s;  // never true: keeps the chains alive
+}
+
+// STREAM triad (measurement utility, ch_bench_triad): grid-stride, 16-byte accesses
+__global__ __launch_bounds__(256) void triad_kernel(double2* __restrict__ a, const double2* __restrict__ b, const double2* __restrict__ c, double s, long n2) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n2; i += 4 * stride) {  // 8 loads in flight per lane before the first use
+    double2 x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { x[u] = b[i + u * stride]; y[u] = c[i + u * stride]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[i + u * stride] = make_double2(x[u].x + s * y[u].x, x[u].y + s * y[u].y);
+  }
+  for (; i < n2; i += stride) { const double2 x = b[i], y = c[i]; a[i] = make_double2(x.x + s * y.x, x.y + s * y.y); }
+}
+
 }  // namespace chip

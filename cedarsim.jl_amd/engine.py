@@ -21,7 +21,7 @@ EXPORTS = [
     "ch_circuit_free", "ch_circuit_info", "ch_circuit_maps", "ch_set_samples", "ch_set_params", "ch_dc", "ch_tran",
     "ch_result_n_times", "ch_result_times", "ch_result_values", "ch_result_final_state", "ch_result_stats",
     "ch_result_status", "ch_result_free", "ch_eval", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
-    "ch_bsim4_param_ignored", "ch_version",
+    "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64",
 ]
 
 _lib = None
@@ -67,6 +67,8 @@ def load_library():
     L.ch_bsim4_param_name.argtypes = [C.c_int32]
     L.ch_bsim4_param_ignored.argtypes = [C.c_char_p]
     L.ch_version.restype = C.c_char_p
+    L.ch_bench_triad.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+    L.ch_bench_fp64.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
     L.ch_dc_opts_default.argtypes = [C.POINTER(ChDcOpts)]
     L.ch_tran_opts_default.argtypes = [C.POINTER(ChTranOpts)]
     _lib = L
@@ -89,6 +91,22 @@ class Context:
 
     def last_error(self):
         return self.L.ch_last_error(self.h).decode()
+
+    def fp64_tflops(self, iters=3):
+        """Measured vector fp64 FMA peak of this GPU in TFLOP/s (measurement utility)."""
+        out = C.c_double(0.0)
+        rc = self.L.ch_bench_fp64(self.h, int(iters), C.byref(out))
+        if rc != 0:
+            raise RuntimeError("ch_bench_fp64 failed: %s" % self.last_error())
+        return out.value
+
+    def triad_gbps(self, n_doubles=1 << 27, iters=5):
+        """Measured STREAM-triad bandwidth of this GPU in GB/s (measurement utility)."""
+        out = C.c_double(0.0)
+        rc = self.L.ch_bench_triad(self.h, int(n_doubles), int(iters), C.byref(out))
+        if rc != 0:
+            raise RuntimeError("ch_bench_triad failed: %s" % self.last_error())
+        return out.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -256,6 +256,14 @@ int32_t ch_bsim4_param_ignored(const char* name); /* 1 if accepted-and-ignored *
 /* ---- library/kernel introspection ---- */
 const char* ch_version(void);
 
+/* ---- measurement utility ("report against ... the builder's own measured STREAM-triad").
+ * a[i] = b[i] + s*c[i] over three fp64 arrays of n_doubles each, `iters` timed passes after one warm-up;
+ * returns the best pass in GB/s (24 bytes per element) in *gbps_out.  No reference counterpart. ---- */
+int ch_bench_triad(ch_ctx*, int64_t n_doubles, int32_t iters, double* gbps_out);
+/* Vector fp64 FMA peak of this GPU, measured: 16 independent v_fma_f64 chains per lane, 8 waves per SIMD;
+ * best of `iters` passes in TFLOP/s (the eval kernel's fp64 rate is reported against this). */
+int ch_bench_fp64(ch_ctx*, int32_t iters, double* tflops_out);
+
 #ifdef __cplusplus
 }
 #endif
