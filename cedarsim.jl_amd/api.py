@@ -5,6 +5,9 @@
     CircuitSweep(builder, sweep)         ≙ CircuitSweep(circuit, sweep)  src/sweeps.jl:390-435
     dc(cs) / tran(cs, tspan)             ≙ dc!(cs) / tran!.(…) broadcast  src/sweeps.jl:448,471-502
     sol.retcode, sol.t, sol["node_q"], sol["r.i"], sol(t, idxs=…), sol.stats   SURVEY §8(b)
+    ac(circuit) → ACSolution.freqresp(sym, ωs)  ≙ ac!(circ), freqresp(ac, sym, ωs)  src/ac.jl:166-177, 267-284
+    noise(circuit) → NoiseSolution.psd(sym, ωs)  ≙ noise!(circ), PSD(noise, sym, ωs) src/ac.jl:178-186, 286-305
+    acdec(nd, fstart, fstop)             ≙ acdec                     src/ac.jl:307-323
 
 The reference loops serially over sweep points, paying a full DC + transient each
 (`broadcast(sims) do sim … remake(prob, p=sim)`, src/sweeps.jl:473-480).  Here every point becomes one
@@ -152,6 +155,100 @@ def tran(circuit, tspan=None, abstol=1e-6, reltol=1e-3, u0=None, initializealg="
     opts = tran_opts(abstol=abstol, reltol=reltol, max_order=max_order, saveat=saveat, dc=dco, skip_dc=u0 is not None, **kw)
     rc, t, v, xf, st = eng.tran(tspan[0], tspan[1], opts)
     return _solutions(ckt, t, v, xf, rc, None, st, 1)[0]
+
+
+def acdec(nd, fstart, fstop):
+    """`.ac dec nd fstart fstop`: log-spaced frequencies in Hz (src/ac.jl:317-322)."""
+    a, b = math.log10(fstart), math.log10(fstop)
+    points = int(math.ceil((b - a) * nd)) + 1
+    return 10.0 ** np.linspace(a, b, points)
+
+
+def _resolve_sym(ckt, sym):
+    """'node_vout' / 'vout' → ('v', node id); 'l3.i' → ('i', device index); 'l3.v' → ('dv', a, b)."""
+    nm = str(sym).lower()
+    if nm.startswith("node_"):
+        nm = nm[5:]
+    if nm in ckt._node_ix:
+        return ("v", ckt._n(nm))
+    if "." in nm:
+        dev, fld = nm.rsplit(".", 1)
+        if dev in ckt.dev_names:
+            i = ckt.dev_names.index(dev)
+            if fld == "v":
+                return ("dv", ckt.dev_node[i][0], ckt.dev_node[i][1])
+            if fld == "i" and ckt.dev_kind[i] in (DEV_V, DEV_L, DEV_VCVS):
+                return ("i", i)
+    raise KeyError(sym)
+
+
+class ACSolution:
+    """Linearisation around the DC operating point, sampled on demand (ACSol, src/ac.jl:10-13)."""
+
+    def __init__(self, circuit, eng, opts):
+        self.circuit, self._eng, self._opts = circuit, eng, opts
+        self.stats = None
+
+    def freqresp(self, sym, omegas, sample=0):
+        """Complex response of `sym` to the circuit's AC sources at angular frequencies `omegas` (rad/s)."""
+        ckt = self.circuit
+        w = np.asarray(omegas, dtype=np.float64)
+        rc, x, st = self._eng.ac(w / (2.0 * math.pi), self._opts)
+        self.stats = st
+        if rc != 0:
+            raise CedarError("AC analysis failed (%s): %s" % (RETCODES.get(rc, rc), self._eng.ctx.last_error()))
+        x = x[sample]
+
+        def node(n):
+            return np.zeros(len(w), complex) if n == 0 else x[:, n - 1]
+
+        r = _resolve_sym(ckt, sym)
+        if r[0] == "v":
+            return node(r[1])
+        if r[0] == "dv":
+            return node(r[1]) - node(r[2])
+        v = x[:, ckt.mna_index("i", ckt.dev_names[r[1]])]
+        if np.any(np.isnan(v)):
+            raise KeyError("branch current of '%s' was eliminated: observe it when building the circuit" % sym)
+        return v
+
+    def bode(self, sym, omegas, sample=0):
+        h = self.freqresp(sym, omegas, sample)
+        return np.abs(h), np.degrees(np.unwrap(np.angle(h))), np.asarray(omegas)
+
+
+class NoiseSolution:
+    """Output-noise analysis around the DC operating point (NoiseSol, src/ac.jl:15-20)."""
+
+    def __init__(self, circuit, eng, opts):
+        self.circuit, self._eng, self._opts = circuit, eng, opts
+        self.stats = None
+
+    def psd(self, sym, omegas, sample=0):
+        """Power spectral density of `sym` (V²/Hz or A²/Hz) at angular frequencies `omegas` — PSD(noise, sym, ωs)."""
+        r = _resolve_sym(self.circuit, sym)
+        if r[0] == "dv":
+            raise CedarError("noise output must be a node voltage or a branch current")
+        w = np.asarray(omegas, dtype=np.float64)
+        rc, out, st = self._eng.noise(0 if r[0] == "v" else 1, r[1], w / (2.0 * math.pi), self._opts)
+        self.stats = st
+        if rc != 0:
+            raise CedarError("noise analysis failed (%s): %s" % (RETCODES.get(rc, rc), self._eng.ctx.last_error()))
+        return out[sample]
+
+
+def ac(circuit, abstol=1e-10, maxiters=200, n_restarts=10, seed=10, ctx=None):
+    """ac!(circ): DC operating point + linearisation; sample it with `.freqresp(sym, ωs)`."""
+    ckt = _prepare(circuit, None)
+    if not any(ckt.source_ac):
+        raise CedarError("AC analysis needs at least one source with an `ac` magnitude")
+    return ACSolution(ckt, EngineCircuit(ckt, ctx), dc_opts(abstol=abstol, maxiters=maxiters, n_restarts=n_restarts, seed=seed))
+
+
+def noise(circuit, abstol=1e-10, maxiters=200, n_restarts=10, seed=10, ctx=None):
+    """noise!(circ): resistor thermal noise referred to an output with `.psd(sym, ωs)`."""
+    ckt = _prepare(circuit, None)
+    return NoiseSolution(ckt, EngineCircuit(ckt, ctx), dc_opts(abstol=abstol, maxiters=maxiters, n_restarts=n_restarts, seed=seed))
 
 
 class CircuitSweep:

@@ -42,7 +42,7 @@ class ChDesc(C.Structure):
         ("n_slot", C.c_int32),
         ("slot_kind", _pi32), ("slot_a", _pi32), ("slot_b", _pi32),
         ("n_obs", C.c_int32),
-        ("obs_kind", _pi32), ("obs_index", _pi32),
+        ("obs_kind", _pi32), ("obs_index", _pi32), ("src_ac", _pf64),
     ]
 
 
@@ -162,6 +162,7 @@ class Circuit:
         self._node_ix = {"0": 0, "gnd": 0, "gnd!": 0}
         self.dev_names, self.dev_kind, self.dev_node, self.dev_ipar, self.dev_par, self.dev_mult = [], [], [], [], [], []
         self.sources = []  # (dc, Wave)
+        self.source_ac = []  # |ac| per source (small-signal magnitude; the phase is ignored, simpledevices.jl:293)
         self.model_names, self.models = [], []
         self.slots, self.slot_names = [], []
         self.obs, self.obs_names = [], []
@@ -207,7 +208,7 @@ class Circuit:
     def L(self, name, a, b, l, m=1.0):
         return self._add(name, DEV_L, (a, b), (l,), m=m)
 
-    def _source(self, dc, tran):
+    def _source(self, dc, tran, ac=0.0):
         # VoltageSource(;dc, tran): dc = something(dc, tran, 0); tran = something(tran, dc) (simpledevices.jl:279-283)
         if tran is not None and not isinstance(tran, Wave):
             tran = DC(tran)
@@ -216,13 +217,14 @@ class Circuit:
         if tran is None:
             tran = DC(dc)
         self.sources.append((float(dc), tran))
+        self.source_ac.append(abs(complex(ac)))
         return len(self.sources) - 1
 
-    def V(self, name, a, b, dc=None, tran=None, m=1.0):
-        return self._add(name, DEV_V, (a, b), ipar=(self._source(dc, tran),), m=m)
+    def V(self, name, a, b, dc=None, tran=None, m=1.0, ac=0.0):
+        return self._add(name, DEV_V, (a, b), ipar=(self._source(dc, tran, ac),), m=m)
 
-    def I(self, name, a, b, dc=None, tran=None, m=1.0):
-        return self._add(name, DEV_I, (a, b), ipar=(self._source(dc, tran),), m=m)
+    def I(self, name, a, b, dc=None, tran=None, m=1.0, ac=0.0):
+        return self._add(name, DEV_I, (a, b), ipar=(self._source(dc, tran, ac),), m=m)
 
     def E(self, name, a, b, c, d, gain=1.0, m=1.0):
         return self._add(name, DEV_VCVS, (a, b, c, d), (gain,), m=m)
@@ -370,6 +372,7 @@ class Circuit:
         d.n_obs = len(self.obs)
         d.obs_kind = arr("o0", [0 if o[0] == "v" else 1 for o in self.obs], np.int32)
         d.obs_index = arr("o1", [o[1] for o in self.obs], np.int32)
+        d.src_ac = arr("sa", self.source_ac, np.float64) if any(self.source_ac) else None
         d._keep = keep
         return d
 

@@ -31,6 +31,7 @@ enum { K_R = 1, K_C, K_L, K_V, K_I, K_VCVS_A, K_VCVS_B, K_VCCS, K_MOS };
 struct HSource {
   int kind;
   double dc;
+  double ac = 0.0;  // small-signal magnitude
   double par[CH_SRC_NPAR];
   std::vector<double> ts, ys;
 };

@@ -211,7 +211,10 @@ struct ch_circuit {
   DevBuf<ClassMeta> d_classes;
   DevBuf<uint16_t> d_gl_src;
   DevBuf<double> d_rate;
-  DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ;  // (d_srcv unused: source values share d_kv)
+  DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ, d_dumpC, d_dumpG, d_dumpF0, d_temp, d_omega, d_xac, d_psd;
+  DevBuf<int> d_noise_a, d_noise_b, d_noise_h, d_acfail;
+  int Stemp = 1;
+  double ac_scale = 0.0;        // eval_sources adds ac_scale*|ac| to every source value (AC right-hand side)  // (d_srcv unused: source values share d_kv)
   DevBuf<unsigned char> d_dmask, d_active;
   DevBuf<BlockOut> d_out;
   DevBuf<Summary> d_sum;
@@ -354,6 +357,10 @@ struct ch_circuit {
     h_src_dc.assign((size_t)Ssrc * nsrc, 0.0); h_src_par.assign((size_t)Ssrc * nsrc * CH_SRC_NPAR, 0.0);
     for (int s = 0; s < Ssrc; ++s) for (int i = 0; i < nsrc; ++i) { h_src_dc[(size_t)s * nsrc + i] = src[i].dc; for (int k = 0; k < CH_SRC_NPAR; ++k) h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR + k] = src[i].par[k]; }
     std::vector<double> hg(Sgmin, gmin);
+    bool any_temp = false;
+    for (int i = 0; i < nslot; ++i) if (slot_set(i) && slot_kind[i] == CH_SLOT_TEMP) any_temp = true;
+    Stemp = any_temp ? S : 1;
+    std::vector<double> htemp(Stemp, temp);
     for (int i = 0; i < nslot; ++i) if (slot_set(i)) {
       const int a = slot_a[i], b = slot_b[i];
       for (int s = 0; s < S; ++s) {
@@ -364,11 +371,12 @@ struct ch_circuit {
           case CH_SLOT_SRC_DC: h_src_dc[(size_t)s * nsrc + a] = v; if (src[a].kind == CH_SRC_DC) h_src_par[((size_t)s * nsrc + a) * CH_SRC_NPAR] = v; break;
           case CH_SLOT_SRC_PAR: h_src_par[((size_t)s * nsrc + a) * CH_SRC_NPAR + b] = v; break;
           case CH_SLOT_GMIN: hg[s] = v; break;
+          case CH_SLOT_TEMP: htemp[s] = v; break;
           default: break;
         }
       }
     }
-    HIPCHK(d_dpar.upload(hpar, st)); HIPCHK(d_dmult.upload(hmult, st)); HIPCHK(d_gmin.upload(hg, st));
+    HIPCHK(d_dpar.upload(hpar, st)); HIPCHK(d_dmult.upload(hmult, st)); HIPCHK(d_gmin.upload(hg, st)); HIPCHK(d_temp.upload(htemp, st));
     // MOS classes: instances with identical (model, geometry, overriding slots) share a column
     const int nmos = (int)A.mos_hdev.size();
     mos_cls.assign(nmos, 0);
@@ -473,7 +481,7 @@ struct ch_circuit {
 #endif
     lds_bytes = (lds_doubles_fixed + A.known.size() + n_dev_src() + (size_t)max_mc * B4I_COUNT) * sizeof(double) + lds_extra_bytes;
     lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
-    path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
+    path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || max_mc > 64 || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
     if (path == 2) {
       if (S != 1) { set_err("the sparse path (Jacobian blocks larger than one CU's LDS) handles one sample at a time"); return CH_ERR_UNSUPPORTED; }
       int rcs = build_sparse_structure();
@@ -499,7 +507,7 @@ struct ch_circuit {
     sv.assign((size_t)Ssrc * nds, 0.0); kv.assign((size_t)Ssrc * nk, 0.0);
     all_src.resize(std::max(1, nsrc));
     for (int s = 0; s < Ssrc; ++s) {
-      for (int i : needed_src) all_src[i] = source_value(src[i], &h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR], h_src_dc[(size_t)s * nsrc + i], t, mode);
+      for (int i : needed_src) all_src[i] = source_value(src[i], &h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR], h_src_dc[(size_t)s * nsrc + i], t, mode) + ac_scale * src[i].ac;
       for (size_t j = 0; j < dev_src.size(); ++j) sv[(size_t)s * nds + j] = all_src[dev_src[j]];
       for (int k = 0; k < nk; ++k) { double v = 0; for (auto& tm : A.known[k].terms) v += tm.second * all_src[tm.first]; kv[(size_t)s * nk + k] = v; }
     }
@@ -1043,6 +1051,7 @@ ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
     HSource s; s.kind = d->src_kind[i]; s.dc = d->src_dc[i];
     for (int k = 0; k < CH_SRC_NPAR; ++k) s.par[k] = d->src_par[i * CH_SRC_NPAR + k];
     if (d->src_pwl_ofs) for (int k = d->src_pwl_ofs[i]; k < d->src_pwl_ofs[i + 1]; ++k) { s.ts.push_back(d->pwl_t[k]); s.ys.push_back(d->pwl_y[k]); }
+    s.ac = d->src_ac ? std::fabs(d->src_ac[i]) : 0.0;
     c->src.push_back(s);
   }
   for (int i = 0; i < d->n_model; ++i) c->model.emplace_back(d->model_par + (size_t)i * CH_B4_NPAR, d->model_par + (size_t)(i + 1) * CH_B4_NPAR);
@@ -1079,6 +1088,8 @@ ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
     if (!ok) return bad("parameter slot refers to a device, model, source or field that does not exist");
     if (k == CH_SLOT_SRC_DC || k == CH_SLOT_SRC_PAR) swept[sa] = 1;
   }
+  // an AC-driven voltage source keeps its node and branch unknowns: the small-signal excitation enters one linear row
+  for (size_t i = 0; i < c->dev.size(); ++i) if (c->dev[i].kind == CH_DEV_V && c->src[c->dev[i].ipar[0]].ac != 0.0) { protect[i] = 1; swept[c->dev[i].ipar[0]] = 1; }
   int rc = analyse(c->n_nodes, c->dev, c->src, protect, swept, c->A);
   if (rc != CH_OK) { ctx->err = c->A.err; delete c; return nullptr; }
   rc = c->upload_structure();
@@ -1196,7 +1207,7 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
   rc = c->set_sources(a, t, mode == 0 ? 0 : 1);
   if (rc != CH_OK) return rc;
   a.mode = MODE_EVAL; a.maxit = 1; a.alpha[0] = alpha0; a.hist_slot[0] = 0; a.cand_slot = 1; a.active = c->d_active.p; a.abstol = 1e-6; a.reltol = 1e-3;
-  a.dumpA = c->d_dumpA.p; a.dumpF = c->d_dumpF.p; a.dumpQ = c->d_dumpQ.p; a.dump_stride = ds;
+  a.dumpA = c->d_dumpA.p; a.dumpF = c->d_dumpF.p; a.dumpQ = c->d_dumpQ.p; a.dumpC = nullptr; a.dump_stride = ds;
   Summary sm;
   rc = c->run_newton(a, act.data(), sm);
   if (rc != CH_OK) return rc;
@@ -1234,6 +1245,148 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
   }
   }
   if (J_out) for (int i = 0; i < n; ++i) if (!has[i]) J_out[(size_t)i * n + i] = 1.0;
+  return CH_OK;
+}
+
+// ---- small-signal analyses -------------------------------------------------------------------
+// Shared front half of ch_ac / ch_noise: DC operating point (slot 0), then G, C (and the AC right-hand
+// side b = -(F(src + ac) - F(src)), exact because every source enters F linearly) as per-block dense dumps.
+static int ac_linearise(ch_circuit* c, const ch_dc_opts* o, ch_stats* st, bool want_b) {
+  int rc = c->finalize_params();
+  if (rc != CH_OK) return rc;
+  if (c->path != 1) { c->set_err("AC / noise analysis needs Jacobian blocks that fit one CU (the sparse path has no complex LU yet)"); return CH_ERR_UNSUPPORTED; }
+  g_arena = &c->arena;
+  rc = c->dc_solve(*o, 0, nullptr, st);
+  if (rc != CH_OK) return rc;
+  const Analysis& A = c->A;
+  const int S = c->S, nblk = A.n_comp * S, ds = A.max_nc;
+  const size_t nA = (size_t)nblk * ds * ds, nF = (size_t)nblk * ds;
+  if (c->d_dumpG.alloc(nA) != hipSuccess || c->d_dumpC.alloc(nA) != hipSuccess || c->d_dumpF0.alloc(nF) != hipSuccess ||
+      c->d_dumpF.alloc(nF) != hipSuccess || c->d_dumpQ.alloc(nF) != hipSuccess || c->d_dumpA.alloc(nA) != hipSuccess) return CH_ERR_DEVICE;
+  const int mode = o->tran_mode ? 2 : 0;
+  for (int pass = 0; pass < (want_b ? 2 : 1); ++pass) {
+    NewtonArgs a = c->base;
+    c->ac_scale = pass == 0 ? 0.0 : 1.0;
+    rc = c->set_sources(a, 0.0, mode);
+    c->ac_scale = 0.0;
+    if (rc != CH_OK) return rc;
+    a.mode = MODE_EVAL; a.maxit = 1; a.alpha[0] = 0.0; a.hist_slot[0] = 0; a.cand_slot = 1; a.active = nullptr; a.abstol = 1e-6; a.reltol = 1e-3;
+    a.dumpA = pass == 0 ? c->d_dumpG.p : c->d_dumpA.p; a.dumpC = pass == 0 ? c->d_dumpC.p : nullptr;
+    a.dumpF = pass == 0 ? c->d_dumpF0.p : c->d_dumpF.p; a.dumpQ = c->d_dumpQ.p; a.dump_stride = ds;
+    Summary sm;
+    rc = c->run_newton(a, nullptr, sm);
+    if (rc != CH_OK) return rc;
+  }
+  if (want_b) {  // b = F0 - F1 (device side, in place in d_dumpF)
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((nF + 255) / 256)), dim3(256), 0, c->ctx->stream, c->d_dumpF.p, (const double*)c->d_dumpF0.p, (long)nF);
+  }
+  return CH_OK;
+}
+
+static int upload_omega(ch_circuit* c, int n_freq, const double* freqs_hz) {
+  std::vector<double> w(n_freq);
+  for (int i = 0; i < n_freq; ++i) { if (!(freqs_hz[i] >= 0.0) || !std::isfinite(freqs_hz[i])) { c->set_err("frequencies must be finite and non-negative"); return CH_ERR_INVALID; } w[i] = 6.283185307179586 * freqs_hz[i]; }
+  if (c->d_omega.upload(w, c->ctx->stream) != hipSuccess) return CH_ERR_DEVICE;
+  std::vector<int> z(1, 0);
+  if (c->d_acfail.upload(z, c->ctx->stream) != hipSuccess) return CH_ERR_DEVICE;
+  return CH_OK;
+}
+
+int ch_ac(ch_circuit* c, const ch_dc_opts* o, int32_t n_freq, const double* freqs_hz, double* x_ac_out, ch_stats* stats) {
+  if (!c || !o || n_freq < 1 || !freqs_hz || !x_ac_out) return CH_ERR_INVALID;
+  c->ctx->err.clear();
+  (void)hipSetDevice(c->ctx->device);
+  auto t0 = hclock::now();
+  ch_stats st; std::memset(&st, 0, sizeof(st));
+  c->device_ms = 0; c->n_launch = 0; c->n_timed = 0;
+  int rc = ac_linearise(c, o, &st, true);
+  st.dc_seconds = std::chrono::duration<double>(hclock::now() - t0).count();
+  if (rc != CH_OK) { if (stats) *stats = st; return rc; }
+  const Analysis& A = c->A;
+  const int S = c->S, nblk = A.n_comp * S, ds = A.max_nc;
+  g_arena = &c->arena;
+  rc = upload_omega(c, n_freq, freqs_hz); if (rc != CH_OK) return rc;
+  const size_t nx = (size_t)S * n_freq * A.n_unk * 2;
+  if (c->d_xac.alloc(nx) != hipSuccess) return CH_ERR_DEVICE;
+  AcArgs a; std::memset(&a, 0, sizeof(a));
+  a.bmeta = c->d_bmeta.p; a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = c->d_dumpF.p; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = A.n_comp;
+  a.omega = c->d_omega.p; a.x_out = c->d_xac.p; a.noise = 0; a.fail = c->d_acfail.p;
+  const size_t lds = (size_t)2 * ds * (ds + 1) * sizeof(double);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ac_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ac_block_kernel, dim3(n_freq, nblk), dim3(64), lds, c->ctx->stream, a);
+  std::vector<double> xs(nx);
+  int fail = 0;
+  if (hipMemcpyAsync(xs.data(), c->d_xac.p, nx * sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(&fail, c->d_acfail.p, sizeof(int), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(c->ctx->stream) != hipSuccess) { c->set_err("AC solve failed on the device"); return CH_ERR_DEVICE; }
+  st.n_kernel_launches = c->n_launch + 2; st.nfactors += (int64_t)n_freq * S; st.nsolve += (int64_t)n_freq * S;
+  // unknown space -> MNA order (known nodes carry no small signal: AC-driven sources are never eliminated)
+  const int n_nodes = c->n_nodes, nm = A.n_mna;
+  for (int s = 0; s < S; ++s) for (int f = 0; f < n_freq; ++f) {
+    const double* xu = &xs[(((size_t)s * n_freq + f) * A.n_unk) * 2];
+    double* xo = x_ac_out + (((size_t)s * n_freq + f) * nm) * 2;
+    for (int n = 1; n <= n_nodes; ++n) { const int u = A.node_unknown[n]; xo[2 * (n - 1)] = u >= 0 ? xu[2 * u] : 0.0; xo[2 * (n - 1) + 1] = u >= 0 ? xu[2 * u + 1] : 0.0; }
+    for (int b = 0; b < A.n_branch; ++b) { const int u = A.branch_unknown[b]; xo[2 * (n_nodes + b)] = u >= 0 ? xu[2 * u] : CH_NAN; xo[2 * (n_nodes + b) + 1] = u >= 0 ? xu[2 * u + 1] : CH_NAN; }
+  }
+  st.wall_seconds = std::chrono::duration<double>(hclock::now() - t0).count();
+  if (stats) *stats = st;
+  if (fail) { c->set_err("AC analysis: singular small-signal matrix G + jwC"); return CH_ERR_SINGULAR; }
+  return CH_OK;
+}
+
+int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_index, int32_t n_freq, const double* freqs_hz, double* psd_out, ch_stats* stats) {
+  if (!c || !o || n_freq < 1 || !freqs_hz || !psd_out) return CH_ERR_INVALID;
+  c->ctx->err.clear();
+  (void)hipSetDevice(c->ctx->device);
+  auto t0 = hclock::now();
+  ch_stats st; std::memset(&st, 0, sizeof(st));
+  c->device_ms = 0; c->n_launch = 0; c->n_timed = 0;
+  const Analysis& A = c->A;
+  int u_out = -1;
+  if (out_kind == 0) { if (out_index < 0 || out_index > c->n_nodes) { c->set_err("noise: output node out of range"); return CH_ERR_INVALID; } u_out = out_index == 0 ? -1 : A.node_unknown[out_index]; }
+  else if (out_kind == 1) {
+    if (out_index < 0 || out_index >= (int)c->dev.size() || c->dev[out_index].branch < 0) { c->set_err("noise: output device has no branch current"); return CH_ERR_INVALID; }
+    u_out = A.branch_unknown[c->dev[out_index].branch];
+    if (u_out < 0) { c->set_err("noise: the output branch current was eliminated (observe it when building the circuit)"); return CH_ERR_INVALID; }
+  } else return CH_ERR_INVALID;
+  int rc = ac_linearise(c, o, &st, false);
+  st.dc_seconds = std::chrono::duration<double>(hclock::now() - t0).count();
+  if (rc != CH_OK) { if (stats) *stats = st; return rc; }
+  const int S = c->S, ds = A.max_nc;
+  if (u_out < 0) {  // a node held by ideal sources carries no noise
+    std::fill(psd_out, psd_out + (size_t)S * n_freq, 0.0);
+    if (stats) *stats = st;
+    return CH_OK;
+  }
+  const int comp = (int)(std::upper_bound(A.comp_uofs.begin(), A.comp_uofs.end(), u_out) - A.comp_uofs.begin()) - 1;
+  const int uofs = A.comp_uofs[comp], ncb = A.comp_nc[comp];
+  std::vector<int> na, nb, nh;
+  for (int d = 0; d < A.comp_ndev[comp]; ++d) {
+    const EDev& e = A.edev[A.comp_dofs[comp] + d];
+    if (e.kind != K_R) continue;
+    auto loc = [&](int t) { return (t >= uofs && t < uofs + ncb) ? t - uofs : -1; };
+    na.push_back(loc(e.term[0])); nb.push_back(loc(e.term[1])); nh.push_back(e.hdev);
+  }
+  g_arena = &c->arena;
+  rc = upload_omega(c, n_freq, freqs_hz); if (rc != CH_OK) return rc;
+  if (c->d_noise_a.upload(na, c->ctx->stream) != hipSuccess || c->d_noise_b.upload(nb, c->ctx->stream) != hipSuccess || c->d_noise_h.upload(nh, c->ctx->stream) != hipSuccess ||
+      c->d_psd.alloc((size_t)S * n_freq) != hipSuccess) return CH_ERR_DEVICE;
+  AcArgs a; std::memset(&a, 0, sizeof(a));
+  a.bmeta = c->d_bmeta.p; a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = nullptr; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = A.n_comp;
+  a.omega = c->d_omega.p; a.noise = 1; a.comp_out = comp; a.row_out = u_out - uofs; a.n_noise = (int)na.size();
+  a.noise_a = c->d_noise_a.p; a.noise_b = c->d_noise_b.p; a.noise_hdev = c->d_noise_h.p; a.dpar = c->d_dpar.p; a.dmult = c->d_dmult.p; a.Spar = c->Spar;
+  a.temp_s = c->d_temp.p; a.Stemp = c->Stemp; a.psd_out = c->d_psd.p; a.fail = c->d_acfail.p;
+  const size_t lds = (size_t)2 * ds * (ds + 1) * sizeof(double);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ac_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ac_block_kernel, dim3(n_freq, S), dim3(64), lds, c->ctx->stream, a);
+  int fail = 0;
+  if (hipMemcpyAsync(psd_out, c->d_psd.p, (size_t)S * n_freq * sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(&fail, c->d_acfail.p, sizeof(int), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(c->ctx->stream) != hipSuccess) { c->set_err("noise solve failed on the device"); return CH_ERR_DEVICE; }
+  st.n_kernel_launches = c->n_launch + 1; st.nfactors += (int64_t)n_freq * S; st.nsolve += (int64_t)n_freq * S;
+  st.wall_seconds = std::chrono::duration<double>(hclock::now() - t0).count();
+  if (stats) *stats = st;
+  if (fail) { c->set_err("noise analysis: singular small-signal matrix G + jwC"); return CH_ERR_SINGULAR; }
   return CH_OK;
 }
 

@@ -88,7 +88,7 @@ struct NewtonArgs {
   double* rate;                              // [n_comp*S] last observed Newton convergence rate per block
   int reset_rate;                            // 1: ignore the stored rates (after a restart / failure)
   double* obs_row;                           // [n_obs][S] candidate row of the observable buffer, or null
-  double* dumpA; double* dumpF; double* dumpQ; int dump_stride;  // MODE_EVAL: per-block dense dumps
+  double* dumpA; double* dumpF; double* dumpQ; double* dumpC; int dump_stride;  // MODE_EVAL: per-block dense dumps (A = G + alpha0*C, C)
   unsigned long long* stamps;                // diagnostic build (-DCH_STAMPS): [block][8] cycle sums, else null
 };
 
@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
           if (a.dumpA) {
             double* dA = a.dumpA + (long)blk * a.dump_stride * a.dump_stride;
             for (int e = lane; e < nc * nc; e += 64) dA[e] = A[(e / nc) * lda + (e % nc)];
+            if (a.dumpC) { double* dC = a.dumpC + (long)blk * a.dump_stride * a.dump_stride; for (int e = lane; e < nc * nc; e += 64) dC[e] = Cm[e]; }
             for (int i = lane; i < nc; i += 64) { a.dumpF[(long)blk * a.dump_stride + i] = Fv[i]; a.dumpQ[(long)blk * a.dump_stride + i] = Qv[i]; }
           }
           for (int i = lane; i < nc; i += 64) qn[i] = Qv[i];
@@ -676,6 +677,118 @@ __global__ __launch_bounds__(64) void mos_eval_quad_kernel(const double* mosp, l
   if (i >= n_mos) return;
   const B4Col P = b4_col(mosp, (long)cls[i] * Smos + (Smos > 1 ? sample : 0));
   b4_device_quad(P, v[4 * i + 0], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], gmin, sub, 1.0, out + (long)i * 40);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Small-signal frequency sweep: (G + jωC) x = b per (block, sample, frequency) — ac! / freqresp
+// (src/ac.jl:75-102, 267-284) and, transposed with a unit right-hand side, the adjoint solve behind
+// noise! / PSD (src/ac.jl:136-163, 286-305).  G, C and b come from MODE_EVAL dumps of the Newton kernel
+// at the DC operating point, so the device arithmetic is the one the transient uses.
+// One wavefront per (frequency, block): complex dense LU with partial pivoting in LDS.
+struct AcArgs {
+  const BlockMeta* bmeta;
+  const double* G; const double* C; const double* b;  // dumps: [nblk][ds][ds], [nblk][ds]
+  int ds, S, n_unk, n_freq, n_comp;
+  const double* omega;                                // [n_freq] rad/s
+  double* x_out;                                      // AC: [S][n_freq][n_unk][2]
+  // noise (adjoint) mode
+  int noise, comp_out, row_out;                       // block and block-local row of the output unknown
+  int n_noise;                                        // thermal-noise resistors of the output block
+  const int* noise_a; const int* noise_b;             // block-local unknown of each terminal or -1 (known node)
+  const int* noise_hdev;                              // host device index (resistance / multiplicity lookup)
+  const double* dpar; const double* dmult; int Spar;
+  const double* temp_s; int Stemp;                    // Celsius per sample
+  double* psd_out;                                    // [S][n_freq]
+  int* fail;                                          // set to 1 when a factorisation breaks down
+};
+
+__global__ __launch_bounds__(64) void ac_block_kernel(const AcArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x, f = blockIdx.x;
+  const int blk = a.noise ? a.comp_out * a.S + (int)blockIdx.y : (int)blockIdx.y;
+  const int c = blk / a.S, s = blk - c * a.S;
+  const BlockMeta bm = a.bmeta[c];
+  const int nc = bm.cm.nc, lda = nc + 1;
+  double* Ar = lds; double* Ai = Ar + (size_t)nc * lda;
+  const double w = a.omega[f];
+  const double* G = a.G + (long)blk * a.ds * a.ds; const double* Cg = a.C + (long)blk * a.ds * a.ds;
+  for (int e = lane; e < nc * nc; e += 64) {
+    const int r = e / nc, col = e - r * nc;
+    const int src = a.noise ? col * nc + r : e;  // adjoint: transpose
+    Ar[r * lda + col] = G[src]; Ai[r * lda + col] = w * Cg[src];
+  }
+  for (int i = lane; i < nc; i += 64) { Ar[i * lda + nc] = a.noise ? (i == a.row_out ? 1.0 : 0.0) : a.b[(long)blk * a.ds + i]; Ai[i * lda + nc] = 0.0; }
+  wave_fence();
+  bool ok = true;
+  for (int k = 0; k < nc && ok; ++k) {
+    double best = -1.0; int bi = k;
+    for (int i = k + lane; i < nc; i += 64) { const double v = fabs(Ar[i * lda + k]) + fabs(Ai[i * lda + k]); if (v > best) { best = v; bi = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (!(best > 0.0) || !(best < 1e300)) { ok = false; break; }
+    if (bi != k) {
+      for (int j = lane; j <= nc; j += 64) {
+        double t = Ar[k * lda + j]; Ar[k * lda + j] = Ar[bi * lda + j]; Ar[bi * lda + j] = t;
+        t = Ai[k * lda + j]; Ai[k * lda + j] = Ai[bi * lda + j]; Ai[bi * lda + j] = t;
+      }
+      wave_fence();
+    }
+    const double pr = Ar[k * lda + k], pi = Ai[k * lda + k];
+    const double den = 1.0 / (pr * pr + pi * pi), ir = pr * den, ii = -pi * den;  // 1/pivot
+    for (int i = k + 1 + lane; i < nc; i += 64) {
+      const double lr = Ar[i * lda + k], li = Ai[i * lda + k];
+      Ar[i * lda + k] = lr * ir - li * ii; Ai[i * lda + k] = lr * ii + li * ir;
+    }
+    wave_fence();
+    const int rem = nc - k - 1, wd = rem + 1;
+    for (int e = lane; e < rem * wd; e += 64) {
+      const int i = k + 1 + e / wd, j = k + 1 + e % wd;
+      const double lr = Ar[i * lda + k], li = Ai[i * lda + k], ur = Ar[k * lda + j], ui = Ai[k * lda + j];
+      Ar[i * lda + j] -= lr * ur - li * ui; Ai[i * lda + j] -= lr * ui + li * ur;
+    }
+    wave_fence();
+  }
+  if (ok) {
+    for (int k = nc - 1; k >= 0; --k) {
+      const double pr = Ar[k * lda + k], pi = Ai[k * lda + k], br = Ar[k * lda + nc], bi_ = Ai[k * lda + nc];
+      const double den = 1.0 / (pr * pr + pi * pi);
+      const double xr = (br * pr + bi_ * pi) * den, xi = (bi_ * pr - br * pi) * den;
+      wave_fence();
+      if (lane == 0) { Ar[k * lda + nc] = xr; Ai[k * lda + nc] = xi; }
+      for (int i = lane; i < k; i += 64) {
+        const double ur = Ar[i * lda + k], ui = Ai[i * lda + k];
+        Ar[i * lda + nc] -= ur * xr - ui * xi; Ai[i * lda + nc] -= ur * xi + ui * xr;
+      }
+      wave_fence();
+    }
+  } else if (lane == 0) *a.fail = 1;
+  if (!a.noise) {
+    double* xo = a.x_out + (((long)s * a.n_freq + f) * a.n_unk + bm.uofs) * 2;
+    for (int i = lane; i < nc; i += 64) { xo[2 * i] = ok ? Ar[i * lda + nc] : CH_NAN; xo[2 * i + 1] = ok ? Ai[i * lda + nc] : CH_NAN; }
+  } else {
+    // output PSD = Σ_k |y_a - y_b|² · 4kT·m/R  (white_noise(dscope, 4kT/res, :thermal), src/simpledevices.jl:72-76)
+    const double T = a.temp_s[a.Stemp > 1 ? s : 0] + 273.15;
+    double acc = 0.0;
+    for (int k = lane; k < a.n_noise; k += 64) {
+      const int na = a.noise_a[k], nb = a.noise_b[k];
+      const double yr = (na >= 0 ? Ar[na * lda + nc] : 0.0) - (nb >= 0 ? Ar[nb * lda + nc] : 0.0);
+      const double yi = (na >= 0 ? Ai[na * lda + nc] : 0.0) - (nb >= 0 ? Ai[nb * lda + nc] : 0.0);
+      const long pi = (long)a.noise_hdev[k] * a.Spar + (a.Spar > 1 ? s : 0);
+      acc += (yr * yr + yi * yi) * 4.0 * 1.380649e-23 * T * a.dmult[pi] / a.dpar[pi];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.psd_out[(long)s * a.n_freq + f] = ok ? acc : CH_NAN;
+  }
+}
+
+// y = x - y (AC right-hand side b = F(src) - F(src + ac))
+__global__ void axpby_kernel(double* y, const double* x, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] - y[i];
 }
 
 // fp64 FMA peak (measurement utility, ch_bench_fp64): 16 independent chains per lane

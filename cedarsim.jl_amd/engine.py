@@ -20,7 +20,7 @@ EXPORTS = [
     "ch_dc_opts_default", "ch_tran_opts_default", "ch_create", "ch_destroy", "ch_last_error", "ch_circuit_build",
     "ch_circuit_free", "ch_circuit_info", "ch_circuit_maps", "ch_set_samples", "ch_set_params", "ch_dc", "ch_tran",
     "ch_result_n_times", "ch_result_times", "ch_result_values", "ch_result_final_state", "ch_result_stats",
-    "ch_result_status", "ch_result_free", "ch_eval", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
+    "ch_result_status", "ch_result_free", "ch_eval", "ch_ac", "ch_noise", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
     "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64",
 ]
 
@@ -66,6 +66,8 @@ def load_library():
     L.ch_bsim4_param_name.restype = C.c_char_p
     L.ch_bsim4_param_name.argtypes = [C.c_int32]
     L.ch_bsim4_param_ignored.argtypes = [C.c_char_p]
+    L.ch_ac.argtypes = [vp, C.POINTER(ChDcOpts), C.c_int32, _pf64, _pf64, C.POINTER(ChStats)]
+    L.ch_noise.argtypes = [vp, C.POINTER(ChDcOpts), C.c_int32, C.c_int32, C.c_int32, _pf64, _pf64, C.POINTER(ChStats)]
     L.ch_version.restype = C.c_char_p
     L.ch_bench_triad.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     L.ch_bench_fp64.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
@@ -207,6 +209,24 @@ class EngineCircuit:
             return rc, t, v, xf, st.asdict()
         finally:
             self.L.ch_result_free(r)
+
+    def ac(self, freqs_hz, opts=None):
+        """Small-signal sweep: complex MNA phasors [S][n_freq][n_mna] for unit excitation of the sources' `ac`."""
+        opts = opts or dc_opts()
+        f = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        out = np.zeros((self.n_samples, len(f), self.n_mna, 2))
+        st = ChStats()
+        rc = self.L.ch_ac(self.h, C.byref(opts), len(f), _p(f), _p(out), C.byref(st))
+        return rc, out[..., 0] + 1j * out[..., 1], st.asdict()
+
+    def noise(self, out_kind, out_index, freqs_hz, opts=None):
+        """Output-noise PSD [S][n_freq] at a node (out_kind 0, node id) or branch current (1, device index)."""
+        opts = opts or dc_opts()
+        f = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        out = np.zeros((self.n_samples, len(f)))
+        st = ChStats()
+        rc = self.L.ch_noise(self.h, C.byref(opts), int(out_kind), int(out_index), len(f), _p(f), _p(out), C.byref(st))
+        return rc, out, st.asdict()
 
     def eval(self, x_mna, t=0.0, alpha0=0.0, mode=1, sample=0):
         x = np.ascontiguousarray(x_mna, dtype=np.float64)

@@ -21,6 +21,7 @@ struct ChDesc
     temp::Float64; gmin::Float64; scale::Float64
     n_slot::Int32; slot_kind::Ptr{Int32}; slot_a::Ptr{Int32}; slot_b::Ptr{Int32}
     n_obs::Int32; obs_kind::Ptr{Int32}; obs_index::Ptr{Int32}
+    src_ac::Ptr{Float64}   # |ac| per source or C_NULL
 end
 struct ChDcOpts
     abstol::Float64; maxiters::Int32; n_restarts::Int32; seed::UInt64; tran_mode::Int32; dv_max::Float64; x0::Ptr{Float64}
@@ -85,6 +86,29 @@ function SciMLBase.__solve(prob::DAEProblem, ::CedarHIPAlg; abstol = 1e-6, relto
     ccall((:ch_result_free, lib), Cvoid, (Ptr{Cvoid},), res[])
     ccall((:ch_circuit_free, lib), Cvoid, (Ptr{Cvoid},), circ)
     CedarHIPSolution(prob, t, v, tbl, retcode(rc))   # getindex(sol, sys.node_q) → column by observable name
+end
+
+# freqresp(ac, sym, ωs) (src/ac.jl:267-284) on the GPU: DC point + linearisation + the whole sweep in one call.
+# Returns the MNA phasors [n_mna, n_freq]; the caller picks the row of `sym` through the observable name map.
+function freqresp_hip(circ_handle::Ptr{Cvoid}, n_mna::Integer, ωs::Vector{Float64}; abstol = 1e-10)
+    dc = ChDcOpts(abstol, 200, 10, 10, false, 2.0, C_NULL)
+    f = ωs ./ 2π
+    out = zeros(Float64, 2, n_mna, length(f))
+    rc = ccall((:ch_ac, lib), Cint, (Ptr{Cvoid}, Ref{ChDcOpts}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+               circ_handle, dc, length(f), f, out, C_NULL)
+    rc == 0 || error(unsafe_string(ccall((:ch_last_error, lib), Cstring, (Ptr{Cvoid},), context())))
+    complex.(out[1, :, :], out[2, :, :])
+end
+
+# PSD(noise, sym, ωs) (src/ac.jl:286-305): out_kind 0 = node voltage (node id), 1 = branch current (device index)
+function psd_hip(circ_handle::Ptr{Cvoid}, out_kind::Integer, out_index::Integer, ωs::Vector{Float64}; abstol = 1e-10)
+    dc = ChDcOpts(abstol, 200, 10, 10, false, 2.0, C_NULL)
+    f = ωs ./ 2π
+    out = zeros(Float64, length(f))
+    rc = ccall((:ch_noise, lib), Cint, (Ptr{Cvoid}, Ref{ChDcOpts}, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+               circ_handle, dc, out_kind, out_index, length(f), f, out, C_NULL)
+    rc == 0 || error(unsafe_string(ccall((:ch_last_error, lib), Cstring, (Ptr{Cvoid},), context())))
+    out
 end
 
 # dc!/tran! keep their signatures (src/sweeps.jl:437-465)

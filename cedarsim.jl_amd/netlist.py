@@ -325,8 +325,8 @@ class ParsedNetlist:
             elif c0 == "l":
                 ckt.L(full, node(pos[0]), node(pos[1]), val(kw["l"]) if "l" in kw else val(pos[2]), m=m)
             elif c0 in "vi":
-                dc, tran = self._source(pos[2:], kw, val)
-                (ckt.V if c0 == "v" else ckt.I)(full, node(pos[0]), node(pos[1]), dc=dc, tran=tran, m=m)
+                dc, tran, ac = self._source(pos[2:], kw, val)
+                (ckt.V if c0 == "v" else ckt.I)(full, node(pos[0]), node(pos[1]), dc=dc, tran=tran, m=m, ac=ac)
             elif c0 == "b":
                 # bsource (spectre_env.jl:127-140): v= / i= / r= / c=
                 a, b = node(pos[0]), node(pos[1])
@@ -389,18 +389,21 @@ class ParsedNetlist:
     @staticmethod
     def _source(rest, kw, val):
         """`[DC] v` / `DC v` / `PWL(...)` / `PULSE(...)` / `SIN(...)` / `AC mag` (src/spectre.jl:1021-1062)."""
-        dc, tran = None, None
+        dc, tran, ac = None, None, 0.0
         i = 0
         rest = list(rest)
         if "dc" in kw:
             dc = val(kw["dc"])
+        if "ac" in kw:
+            ac = val(kw["ac"])
         while i < len(rest):
             t = rest[i]
             tl = t.lower()
             if tl == "dc":
                 dc = val(rest[i + 1])
                 i += 2
-            elif tl == "ac":
+            elif tl == "ac":  # AC mag [phase]: the phase is parsed and ignored (src/simpledevices.jl:293 "TODO phase")
+                ac = val(rest[i + 1]) if i + 1 < len(rest) else 1.0
                 i += 2
                 while i < len(rest) and parse_number(rest[i]) is not None:
                     i += 1
@@ -424,7 +427,7 @@ class ParsedNetlist:
             else:
                 dc = val(t)
                 i += 1
-        return dc, tran
+        return dc, tran, ac
 
 
 def parse_spice(text, include_dirs=(), lib_resolver=None, _into=None, _section=None):

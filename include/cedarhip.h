@@ -124,6 +124,10 @@ typedef struct ch_desc {
   int32_t n_obs;
   const int32_t* obs_kind;  /* [n_obs] 0 = node voltage (index = node id), 1 = branch current (index = device index) */
   const int32_t* obs_index; /* [n_obs] */
+  /* small-signal analysis: |ac| of every source (VoltageSource/CurrentSource `ac`, the phase is ignored as
+   * in src/simpledevices.jl:293,332), or NULL when no source has one.  A voltage source with ac != 0 keeps
+   * its node and branch unknowns (it is never folded into a known node). */
+  const double* src_ac;     /* [n_src] or NULL */
 } ch_desc;
 
 /* Statistics — the fields CedarSim accumulates from NLStats/DEStats (src/dcop.jl:63-67,134-139) */
@@ -252,6 +256,22 @@ int ch_mos_eval_quad(ch_circuit*, int32_t sample, const double* v, double* out);
 int32_t ch_bsim4_npar(void);
 const char* ch_bsim4_param_name(int32_t idx);
 int32_t ch_bsim4_param_ignored(const char* name); /* 1 if accepted-and-ignored */
+
+/* ---- small-signal AC analysis.  Replaces: ac!(circ) + freqresp(ac, sym, ωs) (src/ac.jl:166-177, 75-102,
+ * 267-284): DC operating point with CedarDCOp, linearisation A = ∂F/∂u, E = mass matrix, B = ∂F/∂ϵω, then
+ * C·(jωE − A)⁻¹·B per frequency.  Here: G = ∂i/∂x and C = ∂q/∂x from the same device kernels at the DC
+ * point, and one batched complex LU (G + jωC)·x = b per (block, sample, frequency) on the GPU.
+ * freqs_hz[n_freq]; x_ac_out[n_samples][n_freq][n_mna][2] (re, im) in MNA order, like ch_dc's x_out
+ * (eliminated branch currents are NaN; nodes tied to ground through non-AC sources are 0). ---- */
+int ch_ac(ch_circuit*, const ch_dc_opts*, int32_t n_freq, const double* freqs_hz, double* x_ac_out, ch_stats* stats);
+
+/* ---- output-noise PSD.  Replaces: noise!(circ) + PSD(noise, sym, ωs) (src/ac.jl:136-163, 178-186, 286-305).
+ * Noise sources built: resistor thermal noise, 4kT/R per instance (src/simpledevices.jl:72-76), T = temp + 273.15.
+ * MOSFET noise is not modelled (the BSIM4 noise equations are outside the restated subset).
+ * out_kind/out_index select the observed unknown like ch_desc.obs_kind/obs_index (0 = node voltage, 1 = branch
+ * current); psd_out[n_samples][n_freq] in V²/Hz (A²/Hz), computed with one adjoint solve per frequency. ---- */
+int ch_noise(ch_circuit*, const ch_dc_opts*, int32_t out_kind, int32_t out_index, int32_t n_freq, const double* freqs_hz,
+             double* psd_out, ch_stats* stats);
 
 /* ---- library/kernel introspection ---- */
 const char* ch_version(void);

@@ -26,6 +26,7 @@
 // BSIM4 arithmetic is PARITY UNPINNED (see oracle_bsim4.hpp).
 #include <algorithm>
 #include <chrono>
+#include <complex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,7 @@ struct Rng {
 struct Source {
   int kind;
   double dc;
+  double ac = 0.0;  // |ac| (src/simpledevices.jl:293: spec.ϵω * abs(VS.ac))
   double par[CH_SRC_NPAR];
   std::vector<double> ts, ys;
 };
@@ -626,6 +628,36 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
   return status;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Small-signal analyses (src/ac.jl).  ACSol: dss(Ju, M, B, I, 0) with B = ∂F/∂ϵω, sampled as
+// C·(jωE − A)⁻¹·B (:75-102, :267-284); here the same linear system in MNA form:
+// (G + jωC)·X = −∂F/∂ϵ, the excitation being ϵ·|ac| added to every source value (simpledevices.jl:292-294).
+typedef std::complex<double> cplx;
+static bool csolve(std::vector<cplx>& A, int n, std::vector<cplx>& b) {  // dense complex LU, partial pivoting
+  for (int k = 0; k < n; ++k) {
+    int p = k; double best = std::abs(A[(size_t)k * n + k]);
+    for (int i = k + 1; i < n; ++i) { double v = std::abs(A[(size_t)i * n + k]); if (v > best) { best = v; p = i; } }
+    if (!(best > 0.0) || !std::isfinite(best)) return false;
+    if (p != k) { for (int j = 0; j < n; ++j) std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]); std::swap(b[k], b[p]); }
+    for (int i = k + 1; i < n; ++i) {
+      cplx l = A[(size_t)i * n + k] / A[(size_t)k * n + k];
+      if (l == cplx(0.0)) continue;
+      for (int j = k; j < n; ++j) A[(size_t)i * n + j] -= l * A[(size_t)k * n + j];
+      b[i] -= l * b[k];
+    }
+  }
+  for (int k = n - 1; k >= 0; --k) { cplx sacc = b[k]; for (int j = k + 1; j < n; ++j) sacc -= A[(size_t)k * n + j] * b[j]; b[k] = sacc / A[(size_t)k * n + k]; }
+  return true;
+}
+// −∂F/∂ϵ, analytic: V source branch row F = va − vb − (dc + ϵ|ac|); I source KCL rows ±m(dc + ϵ|ac|)
+static void ac_rhs(const Circuit& c, std::vector<double>& b) {
+  b.assign(c.n, 0.0);
+  for (const Device& d : c.dev) {
+    if (d.kind == CH_DEV_V) b[c.n_nodes + d.branch] += c.src[d.ipar[0]].ac;
+    else if (d.kind == CH_DEV_I) { const double i = d.mult * c.src[d.ipar[0]].ac; if (d.node[0]) b[d.node[0] - 1] -= i; if (d.node[1]) b[d.node[1] - 1] += i; }
+  }
+}
 }  // namespace oracle
 
 // =============================================================================================
@@ -642,6 +674,7 @@ void* oracle_build(const ch_desc* d) {
     Source s; s.kind = d->src_kind[i]; s.dc = d->src_dc[i];
     for (int k = 0; k < CH_SRC_NPAR; ++k) s.par[k] = d->src_par[i * CH_SRC_NPAR + k];
     if (d->src_pwl_ofs) for (int k = d->src_pwl_ofs[i]; k < d->src_pwl_ofs[i + 1]; ++k) { s.ts.push_back(d->pwl_t[k]); s.ys.push_back(d->pwl_y[k]); }
+    s.ac = d->src_ac ? std::fabs(d->src_ac[i]) : 0.0;
     c->src.push_back(s);
   }
   for (int i = 0; i < d->n_model; ++i) c->model.emplace_back(d->model_par + (size_t)i * CH_B4_NPAR, d->model_par + (size_t)(i + 1) * CH_B4_NPAR);
@@ -695,6 +728,55 @@ int oracle_dc(void* h, const ch_dc_opts* o, double* x_out, ch_stats* st) {
   if (x_out) for (int i = 0; i < c->n; ++i) x_out[i] = (i < (int)x.size()) ? x[i] : 0.0;
   if (st) *st = local;
   return rc;
+}
+
+// ac!(circ) + freqresp(ac, ·, ωs): x_out[n_freq][n][2] (re, im), MNA order
+int oracle_ac(void* h, const ch_dc_opts* o, int n_freq, const double* freqs_hz, double* x_out) {
+  Circuit* c = (Circuit*)h;
+  std::vector<double> x;
+  int rc = dc_solve(*c, *o, x, nullptr);
+  if (rc != CH_OK) return rc;
+  const int n = c->n;
+  Eval e; evaluate(*c, x.data(), 0.0, o->tran_mode ? 2 : 0, e);
+  std::vector<double> b; ac_rhs(*c, b);
+  for (int f = 0; f < n_freq; ++f) {
+    const double w = 6.283185307179586 * freqs_hz[f];
+    std::vector<cplx> A((size_t)n * n), r(n);
+    for (size_t k = 0; k < A.size(); ++k) A[k] = cplx(e.G[k], w * e.C[k]);
+    for (int i = 0; i < n; ++i) r[i] = b[i];
+    if (!csolve(A, n, r)) { c->err = "singular small-signal matrix"; return CH_ERR_SINGULAR; }
+    for (int i = 0; i < n; ++i) { x_out[((size_t)f * n + i) * 2] = r[i].real(); x_out[((size_t)f * n + i) * 2 + 1] = r[i].imag(); }
+  }
+  return CH_OK;
+}
+
+// noise!(circ) + PSD(noise, sym, ωs) (src/ac.jl:286-305): Σ_k |H_k(jω)|²·pwr_k with pwr = 4kT/res per resistor
+// (src/simpledevices.jl:72-76).  Direct method: one solve per noise source (the engine uses the adjoint).
+int oracle_noise(void* h, const ch_dc_opts* o, int out_mna, int n_freq, const double* freqs_hz, double* psd_out) {
+  Circuit* c = (Circuit*)h;
+  std::vector<double> x;
+  int rc = dc_solve(*c, *o, x, nullptr);
+  if (rc != CH_OK) return rc;
+  const int n = c->n;
+  if (out_mna < 0 || out_mna >= n) return CH_ERR_INVALID;
+  Eval e; evaluate(*c, x.data(), 0.0, o->tran_mode ? 2 : 0, e);
+  const double kB = 1.380649e-23, T = c->temp + 273.15;
+  for (int f = 0; f < n_freq; ++f) {
+    const double w = 6.283185307179586 * freqs_hz[f];
+    double acc = 0.0;
+    for (const Device& d : c->dev) {
+      if (d.kind != CH_DEV_R) continue;
+      std::vector<cplx> A((size_t)n * n), r(n, cplx(0.0));
+      for (size_t k = 0; k < A.size(); ++k) A[k] = cplx(e.G[k], w * e.C[k]);
+      // unit noise current from node a to node b through the source: leaves a (F_a += 1), enters b
+      if (d.node[0]) r[d.node[0] - 1] -= 1.0;
+      if (d.node[1]) r[d.node[1] - 1] += 1.0;
+      if (!csolve(A, n, r)) { c->err = "singular small-signal matrix"; return CH_ERR_SINGULAR; }
+      acc += std::norm(r[out_mna]) * 4.0 * kB * T * d.mult / d.par[0];
+    }
+    psd_out[f] = acc;
+  }
+  return CH_OK;
 }
 
 void* oracle_tran(void* h, double t0, double t1, const ch_tran_opts* o) {

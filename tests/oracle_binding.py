@@ -37,6 +37,8 @@ def lib():
     L.oracle_result_status.argtypes = [C.c_void_p]
     L.oracle_result_stats.argtypes = [C.c_void_p, C.POINTER(ChStats)]
     L.oracle_result_free.argtypes = [C.c_void_p]
+    L.oracle_ac.argtypes = [C.c_void_p, C.POINTER(ChDcOpts), C.c_int, _pf64, _pf64]
+    L.oracle_noise.argtypes = [C.c_void_p, C.POINTER(ChDcOpts), C.c_int, C.c_int, _pf64, _pf64]
     L.oracle_eval.argtypes = [C.c_void_p, _pf64, C.c_double, C.c_double, C.c_int, _pf64, _pf64, _pf64]
     L.oracle_mos_eval.argtypes = [C.c_void_p, _pf64, _pf64]
     L.oracle_mos_eval_values.argtypes = [C.c_void_p, _pf64, _pf64]
@@ -73,6 +75,20 @@ class Oracle:
         st = ChStats()
         rc = self.L.oracle_dc(self.h, C.byref(opts), _p(x), C.byref(st))
         return rc, x, st.asdict()
+
+    def ac(self, freqs_hz, opts=None):
+        opts = opts or dc_opts()
+        f = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        out = np.zeros((len(f), self.n, 2))
+        rc = self.L.oracle_ac(self.h, C.byref(opts), len(f), _p(f), _p(out))
+        return rc, out[..., 0] + 1j * out[..., 1]
+
+    def noise(self, out_mna, freqs_hz, opts=None):
+        opts = opts or dc_opts()
+        f = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        out = np.zeros(len(f))
+        rc = self.L.oracle_noise(self.h, C.byref(opts), int(out_mna), len(f), _p(f), _p(out))
+        return rc, out
 
     def tran(self, t0, t1, opts=None):
         opts = opts or tran_opts()

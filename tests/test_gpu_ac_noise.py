@@ -1,0 +1,145 @@
+"""GPU parity tests of the small-signal analyses (ch_ac / ch_noise through the C-ABI): the reference's
+closed forms and ngspice table (test/ac.jl:17-148), and the CPU oracle on nonlinear circuits."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cedarsim_jl_amd import Circuit, ac, acdec, dc_opts, noise
+from cedarsim_jl_amd.workloads import gf180_models
+
+from test_ac_noise_oracle import C2, L1, L3, R4, butterworth_circuit
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def E():
+    from cedarsim_jl_amd.engine import EngineCircuit, load_library
+    load_library()
+    return EngineCircuit
+
+
+@pytest.fixture(scope="module")
+def O(oracle_lib):
+    from oracle_binding import Oracle
+    return Oracle
+
+
+def test_ac_butterworth_closed_form():
+    sol = ac(butterworth_circuit())
+    w = 2 * math.pi * acdec(20, 0.01, 10)
+    s = 1j * w
+    H = 1.0 / ((s + 1) * (s * s + s + 1))
+    assert np.allclose(sol.freqresp("node_vout", w), H, rtol=1e-9, atol=0)        # test/ac.jl:47
+    assert np.allclose(sol.freqresp("node_vin", w), 1.0, rtol=1e-12)               # :49
+    assert np.allclose(sol.freqresp("l3.v", w), s * L3 * H, rtol=1e-9, atol=0)     # :61-64
+    mag, ph, _ = sol.bode("node_vout", w)
+    assert np.allclose(mag, np.abs(H), rtol=1e-9) and np.allclose(ph, np.degrees(np.unwrap(np.angle(H))), atol=1e-7)
+
+
+def test_noise_butterworth_analytic_and_ngspice():
+    gold = json.load(open(os.path.join(HERE, "golden", "ac_butterworth_noise_ngspice.json")))
+    ng = np.array([r[1] for r in gold["rows"]])
+    w = 2 * math.pi * acdec(20, 0.01, 10)
+    psd = noise(butterworth_circuit()).psd("node_vout", w)
+    s = 1j * w
+    par = lambda a, b: a * b / (a + b)  # noqa: E731
+    H = par(par(s * L1, 1 / (s * C2)) + s * L3, R4)
+    apsd = np.sqrt(np.abs(4 * 1.380649e-23 * (23 + 273.15) / R4 * H * H))
+    assert np.allclose(np.sqrt(psd), apsd, rtol=1e-6)     # test/ac.jl:148
+    assert np.allclose(np.sqrt(psd), ng, rtol=1e-6)       # against the ngspice table itself
+
+
+def amp_circuit():
+    """Common-source NMOS stage with a resistive load, a current-source bias and an RC-coupled AC input."""
+    c = Circuit(gmin=1e-12)
+    c.temp = 40.0
+    m = gf180_models()
+    n = c.add_model(*m["nfet_06v0"])
+    p = c.add_model(*m["pfet_06v0"])
+    c.V("vdd", "vdd", 0, dc=5.0)
+    c.V("vin", "in", 0, dc=0.0, ac=1.0)
+    c.C("cin", "in", "g", 1e-9)
+    c.R("rb1", "vdd", "g", 300e3, m=2.0)
+    c.R("rb2", "g", 0, 100e3)
+    c.M("m1", "d", "g", "s", 0, n, 2e-6, 6e-7)
+    c.R("rd", "vdd", "d", 20e3)
+    c.R("rs", "s", 0, 1e3)
+    c.C("cs", "s", 0, 1e-9)
+    c.M("m2", "o", "d", "vdd", "vdd", p, 4e-6, 5e-7)   # PMOS follower-ish second stage
+    c.R("ro", "o", 0, 50e3)
+    c.C("co", "o", 0, 1e-12)
+    c.I("iinj", "d", 0, dc=1e-6, ac=0.0)
+    return c
+
+
+def test_ac_nonlinear_amplifier_matches_oracle(E, O):
+    ckt = amp_circuit()
+    ckt.observe_all_nodes()
+    f = acdec(5, 1e2, 1e10)
+    rc_o, xo = O(ckt).ac(f, dc_opts(abstol=1e-12))
+    rc, xe, st = E(ckt).ac(f, dc_opts(abstol=1e-12))
+    assert rc == 0 and rc_o == 0
+    xe = xe[0]
+    gain = np.abs(xe[:, ckt._n("o") - 1])
+    assert gain.max() > 1.0                                     # it does amplify
+    for node in ("g", "d", "s", "o", "in"):
+        a, b = xe[:, ckt._n(node) - 1], xo[:, ckt._n(node) - 1]
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-12 * np.abs(b).max()), node
+    # branch current of the AC source (kept as an unknown)
+    k = ckt.mna_index("i", "vin")
+    assert np.allclose(xe[:, k], xo[:, k], rtol=1e-6, atol=1e-18)
+
+
+def test_noise_nonlinear_amplifier_matches_oracle(E, O):
+    ckt = amp_circuit()
+    ckt.observe_all_nodes()
+    f = acdec(5, 1e2, 1e10)
+    for node in ("o", "d"):
+        rc_o, po = O(ckt).noise(ckt._n(node) - 1, f, dc_opts(abstol=1e-12))
+        rc, pe, st = E(ckt).noise(0, ckt._n(node), f, dc_opts(abstol=1e-12))
+        assert rc == 0 and rc_o == 0
+        assert np.all(pe[0] > 0)
+        assert np.allclose(pe[0], po, rtol=1e-6), node
+    # a node held by an ideal source is noiseless
+    rc, pe, st = E(ckt).noise(0, ckt._n("vdd"), f)
+    assert rc == 0 and np.all(pe == 0.0)
+
+
+def test_ac_current_source_and_batched_samples(E, O):
+    """I-source excitation into a parallel RC; R swept over 8 samples in one batched call: Z = R/(1+jwRC)."""
+    c = Circuit()
+    c.I("i1", 0, "a", dc=0.0, ac=2.0)
+    c.R("r1", "a", 0, 1e3)
+    c.C("c1", "a", 0, 1e-9)
+    c.observe_node("a")
+    slot = c.slot("r1", "r")
+    eng = E(c)
+    rs = np.linspace(500.0, 4000.0, 8)
+    eng.set_samples(8)
+    eng.set_params([slot], [list(rs)])
+    f = acdec(10, 1e3, 1e7)
+    rc, x, st = eng.ac(f)
+    assert rc == 0
+    w = 2 * math.pi * f
+    for s, r in enumerate(rs):
+        z = 2.0 * r / (1 + 1j * w * r * 1e-9)
+        assert np.allclose(x[s, :, 0], z, rtol=1e-10)
+    # thermal noise of the same R: 4kTR/(1+(wRC)^2)
+    rc, psd, st = eng.noise(0, c._n("a"), f)
+    assert rc == 0
+    for s, r in enumerate(rs):
+        assert np.allclose(psd[s], 4 * 1.380649e-23 * (27 + 273.15) * r / (1 + (w * r * 1e-9) ** 2), rtol=1e-10)
+
+
+def test_ac_requires_a_source_and_small_blocks():
+    from cedarsim_jl_amd import CedarError
+    c = Circuit()
+    c.V("v1", "a", 0, dc=1.0)
+    c.R("r1", "a", 0, 1.0)
+    with pytest.raises(CedarError):
+        ac(c)
