@@ -14,8 +14,8 @@ import numpy as np
 from . import bsim4_params as B4
 
 # ---- enums of include/cedarhip.h -------------------------------------------------------------
-DEV_R, DEV_C, DEV_L, DEV_V, DEV_I, DEV_VCVS, DEV_VCCS, DEV_MOS = 1, 2, 3, 4, 5, 6, 7, 8
-DEV_NNODE, DEV_NPAR, DEV_NIPAR = 4, 8, 2
+DEV_R, DEV_C, DEV_L, DEV_V, DEV_I, DEV_VCVS, DEV_VCCS, DEV_MOS, DEV_VA = 1, 2, 3, 4, 5, 6, 7, 8, 9
+DEV_NNODE, DEV_NPAR, DEV_NIPAR = 8, 8, 2
 MOS_W, MOS_L, MOS_NF, MOS_AS, MOS_AD, MOS_PS, MOS_PD = 0, 1, 2, 3, 4, 5, 6
 SRC_DC, SRC_PWL, SRC_PULSE, SRC_SIN = 0, 1, 2, 3
 SRC_NPAR = 8
@@ -42,7 +42,7 @@ class ChDesc(C.Structure):
         ("n_slot", C.c_int32),
         ("slot_kind", _pi32), ("slot_a", _pi32), ("slot_b", _pi32),
         ("n_obs", C.c_int32),
-        ("obs_kind", _pi32), ("obs_index", _pi32), ("src_ac", _pf64),
+        ("obs_kind", _pi32), ("obs_index", _pi32), ("src_ac", _pf64), ("n_va_par", C.c_int64), ("va_par", _pf64),
     ]
 
 
@@ -166,6 +166,8 @@ class Circuit:
         self.model_names, self.models = [], []
         self.slots, self.slot_names = [], []
         self.obs, self.obs_names = [], []
+        self.va_par = []       # parameter blocks of the compiled Verilog-A instances (values, then $param_given flags)
+        self.va_instances = {}  # device name -> (module, resolved parameters)
 
     # -- nets --
     def net(self, name):
@@ -231,6 +233,36 @@ class Circuit:
 
     def G(self, name, a, b, c, d, gain=1.0, m=1.0):
         return self._add(name, DEV_VCCS, (a, b, c, d), (gain,), m=m)
+
+    def VA(self, name, module, nodes, params=None, m=1.0):
+        """Instance of a compiled Verilog-A module — the device functor `make_spice_device` builds from the module
+        (src/vasim.jl:649-867).  `nodes` are the ports in declaration order; internal nets become circuit nodes
+        `<name>.<net>`; `V(a,b) <+ 0` contributions that the parameter set activates merge their nodes."""
+        from .va.interp import Interp
+        from .va.registry import find_module
+        mid, mod = find_module(module)
+        name = str(name).lower()
+        if len(nodes) != len(mod.ports):
+            raise CedarError("module %s has %d ports, %d nodes given" % (mod.name, len(mod.ports), len(nodes)))
+        it = Interp(mod, params or {}, temperature_c=self.temp, gmin=self.gmin)
+        all_nodes = [self._n(x) for x in nodes] + [self.net("%s.%s" % (name, n)) for n in mod.internal]
+        ofs = len(self.va_par)
+        for pname, ty, _, _ in mod.params:
+            self.va_par.append(float(it.params[pname]) if ty != "string" else 0.0)
+        for pname, ty, _, _ in mod.params:
+            self.va_par.append(1.0 if pname in it.given else 0.0)
+        # structure probe: which voltage contributions (node collapses) does this parameter set execute?
+        it.evaluate({})
+        k = 0
+        for acc, nds, kind in it.structure:
+            if acc == "V":
+                if len(nds) != 2:
+                    raise CedarError("V(%s) <+ 0 to ground is not supported" % nds[0])
+                a, b = (all_nodes[mod.nodes.index(x)] for x in nds)
+                self.V("%s.collapse%d" % (name, k), a, b, dc=0.0)
+                k += 1
+        self.va_instances[name] = (mod, it.params)
+        return self._add(name, DEV_VA, all_nodes, ipar=(mid, ofs), m=m)
 
     def add_model(self, name, mtype, params):
         """BSIM4 card.  mtype 'nmos'|'pmos' → TYPE=±1 (src/spectre.jl:632-643)."""
@@ -373,6 +405,8 @@ class Circuit:
         d.obs_kind = arr("o0", [0 if o[0] == "v" else 1 for o in self.obs], np.int32)
         d.obs_index = arr("o1", [o[1] for o in self.obs], np.int32)
         d.src_ac = arr("sa", self.source_ac, np.float64) if any(self.source_ac) else None
+        d.n_va_par = len(self.va_par)
+        d.va_par = arr("vp", self.va_par, np.float64) if self.va_par else None
         d._keep = keep
         return d
 

@@ -26,7 +26,8 @@
 namespace chip {
 
 // engine-internal device kinds (VCVS is split into its branch part and its control part)
-enum { K_R = 1, K_C, K_L, K_V, K_I, K_VCVS_A, K_VCVS_B, K_VCCS, K_MOS };
+enum { K_R = 1, K_C, K_L, K_V, K_I, K_VCVS_A, K_VCVS_B, K_VCCS, K_MOS, K_VA };
+constexpr int NTERM = 8;  // terminals of an engine device record (compiled Verilog-A modules use up to 8 nodes)
 
 struct HSource {
   int kind;
@@ -42,6 +43,8 @@ struct HDev {
   int ipar[CH_DEV_NIPAR];
   double par[CH_DEV_NPAR];
   double mult;
+  int va_nt = 0;          // CH_DEV_VA: nodes of the compiled module
+  unsigned va_qmask = 0;  // CH_DEV_VA: nodes touched by ddt() contributions
   int branch;      // MNA branch index or -1
   bool eliminated; // V source removed by known/alias analysis
 };
@@ -53,7 +56,9 @@ struct KnownDef {  // value(t) = sum_j sign_j * src_j(t)
 // one engine device record (what a lane evaluates)
 struct EDev {
   int kind;
-  int term[4];   // >= 0: global unknown index; < 0: -(known index + 1)
+  int term[NTERM];   // >= 0: global unknown index; < 0: -(known index + 1)
+  int nt = 4;        // terminals in use (K_VA: nodes of the module)
+  unsigned qmask = 0; // K_VA: nodes that receive ddt() contributions
   int hdev;      // index into the description's device list (parameters, multiplier)
   int src;       // source index or -1
   int mos;       // MOS instance index or -1
@@ -63,7 +68,7 @@ struct CompClass {
   int nc = 0, ndev = 0;
   bool nonlinear = false;                  // contains a MOSFET: DC Newton steps are voltage-limited
   std::vector<int> mat_ptr, vec_ptr;       // CSR over nc*nc matrix targets / nc vector targets
-  std::vector<uint16_t> mat_src, vec_src;  // staging offsets dev_local*40 + slot (G block / F block)
+  std::vector<uint16_t> mat_src, vec_src;  // staging offsets dev_local*stride + slot (G block / F block)
 };
 
 struct Analysis {
@@ -82,22 +87,27 @@ struct Analysis {
   std::vector<EDev> edev;          // component-ordered
   std::vector<CompClass> classes;
   int max_nc = 0, max_ndev = 0;
+  bool wide = false;               // a compiled Verilog-A device is present: stamp records are [I(8)|Q(8)|G(64)|C(64)]
+  int stride() const { return wide ? 144 : 40; }
+  int g_ofs() const { return wide ? 16 : 8; }
+  int g_ld() const { return wide ? 8 : 4; }
   std::vector<int> mos_hdev;       // MOS instance -> description device index
   std::string err;
 };
 
-// slot mask per engine kind: which of the 4 vector slots / 16 matrix slots a device writes
-inline void kind_mask(int kind, bool vec[4], bool mat[16]) {
-  for (int i = 0; i < 4; ++i) vec[i] = false;
-  for (int i = 0; i < 16; ++i) mat[i] = false;
-  auto M = [&](int r, int c) { mat[r * 4 + c] = true; };
+// slot mask per engine kind: which of the NTERM vector slots / NTERM² matrix slots a device writes
+inline void kind_mask(int kind, bool vec[NTERM], bool mat[NTERM * NTERM], int nt = 4) {
+  for (int i = 0; i < NTERM; ++i) vec[i] = false;
+  for (int i = 0; i < NTERM * NTERM; ++i) mat[i] = false;
+  auto M = [&](int r, int c) { mat[r * NTERM + c] = true; };
   switch (kind) {
     case K_R: case K_C: vec[0] = vec[1] = true; M(0, 0); M(0, 1); M(1, 0); M(1, 1); break;
     case K_I: vec[0] = vec[1] = true; break;
     case K_V: case K_L: case K_VCVS_A: vec[0] = vec[1] = vec[2] = true; M(0, 2); M(1, 2); M(2, 0); M(2, 1); M(2, 2); break;
     case K_VCVS_B: vec[0] = true; M(0, 1); M(0, 2); break;
     case K_VCCS: vec[0] = vec[1] = true; M(0, 2); M(0, 3); M(1, 2); M(1, 3); break;
-    case K_MOS: for (int i = 0; i < 4; ++i) vec[i] = true; for (int i = 0; i < 16; ++i) mat[i] = true; break;
+    case K_MOS: for (int i = 0; i < 4; ++i) { vec[i] = true; for (int j = 0; j < 4; ++j) M(i, j); } break;
+    case K_VA: for (int i = 0; i < nt; ++i) { vec[i] = true; for (int j = 0; j < nt; ++j) M(i, j); } break;
   }
 }
 
@@ -183,7 +193,8 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     const HDev& d = dev[i];
     if (d.eliminated) continue;
     EDev e; e.hdev = (int)i; e.src = -1; e.mos = -1;
-    for (int k = 0; k < 4; ++k) e.term[k] = -1;  // known 0 = ground
+    for (int k = 0; k < NTERM; ++k) e.term[k] = -1;  // known 0 = ground
+    e.nt = 4; e.qmask = 0;
     switch (d.kind) {
       case CH_DEV_R: e.kind = K_R; e.term[0] = term_of_node(d.node[0]); e.term[1] = term_of_node(d.node[1]); recs.push_back(e); break;
       case CH_DEV_C: e.kind = K_C; e.term[0] = term_of_node(d.node[0]); e.term[1] = term_of_node(d.node[1]); recs.push_back(e); break;
@@ -196,6 +207,11 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
       } break;
       case CH_DEV_VCCS: e.kind = K_VCCS; for (int k = 0; k < 4; ++k) e.term[k] = term_of_node(d.node[k]); recs.push_back(e); break;
       case CH_DEV_MOS: e.kind = K_MOS; e.mos = (int)A.mos_hdev.size(); A.mos_hdev.push_back((int)i); for (int k = 0; k < 4; ++k) e.term[k] = term_of_node(d.node[k]); recs.push_back(e); break;
+      case CH_DEV_VA: {
+        e.kind = K_VA; e.nt = d.va_nt; e.qmask = d.va_qmask; A.wide = true;
+        for (int k = 0; k < e.nt; ++k) e.term[k] = term_of_node(d.node[k]);
+        recs.push_back(e);
+      } break;
       default: A.err = "unknown device kind"; return CH_ERR_INVALID;
     }
   }
@@ -205,7 +221,7 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
   std::vector<char> touched(nprov, 0);
   for (const EDev& e : recs) {
     int first = -1;
-    for (int k = 0; k < 4; ++k) if (e.term[k] >= 0) { touched[e.term[k]] = 1; if (first < 0) first = e.term[k]; else cu.unite(first, e.term[k]); }
+    for (int k = 0; k < NTERM; ++k) if (e.term[k] >= 0) { touched[e.term[k]] = 1; if (first < 0) first = e.term[k]; else cu.unite(first, e.term[k]); }
   }
   for (int u = 0; u < nprov; ++u) if (!touched[u]) { A.err = "floating node without any device"; return CH_ERR_SINGULAR; }
   std::map<int, int> comp_of_root;
@@ -242,7 +258,7 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
   for (size_t i = 0; i < recs.size(); ++i) {
     EDev& e = recs[i];
     int c = -1;
-    for (int k = 0; k < 4; ++k) if (e.term[k] >= 0) { c = comp_id[e.term[k]]; e.term[k] = fin[e.term[k]]; }
+    for (int k = 0; k < NTERM; ++k) if (e.term[k] >= 0) { c = comp_id[e.term[k]]; e.term[k] = fin[e.term[k]]; }
     if (c >= 0) cdev[c].push_back((int)i);  // devices between known nodes only do not enter the system
   }
   A.comp_dofs.assign(A.n_comp, 0);
@@ -261,6 +277,7 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     if (e.kind == K_C) { mark(e.term[0]); mark(e.term[1]); }
     else if (e.kind == K_L) mark(e.term[2]);
     else if (e.kind == K_MOS) for (int k = 0; k < 4; ++k) mark(e.term[k]);
+    else if (e.kind == K_VA) for (int k = 0; k < e.nt; ++k) if (e.qmask & (1u << k)) mark(e.term[k]);
   }
 
   // ---- 4: classes + gather lists ----
@@ -273,7 +290,8 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     for (int i = 0; i < A.comp_ndev[c]; ++i) {
       const EDev& e = A.edev[A.comp_dofs[c] + i];
       sig.push_back(e.kind);
-      for (int k = 0; k < 4; ++k) sig.push_back(e.term[k] >= 0 ? e.term[k] - A.comp_uofs[c] : -1);
+      for (int k = 0; k < NTERM; ++k) sig.push_back(e.term[k] >= 0 ? e.term[k] - A.comp_uofs[c] : -1);
+      sig.push_back(e.nt);
     }
     auto it = class_of_sig.find(sig);
     if (it != class_of_sig.end()) { A.comp_class[c] = it->second; continue; }
@@ -282,18 +300,19 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     A.comp_class[c] = id;
     CompClass cl;
     cl.nc = A.comp_nc[c]; cl.ndev = A.comp_ndev[c];
-    if ((long)cl.ndev * 40 > 65535) { A.err = "component too large for 16-bit staging offsets"; return CH_ERR_UNSUPPORTED; }
+    const int stride = A.stride(), gofs = A.g_ofs(), gld = A.g_ld();
+    if ((long)cl.ndev * stride > 65535) { A.err = "component too large for 16-bit staging offsets"; return CH_ERR_UNSUPPORTED; }
     std::vector<std::vector<uint16_t>> ml((size_t)cl.nc * cl.nc), vl(cl.nc);
     for (int i = 0; i < cl.ndev; ++i) {
       const EDev& e = A.edev[A.comp_dofs[c] + i];
-      bool vm[4], mm[16];
-      kind_mask(e.kind, vm, mm);
-      if (e.kind == K_MOS) cl.nonlinear = true;
-      int row[4];
-      for (int k = 0; k < 4; ++k) row[k] = e.term[k] >= 0 ? e.term[k] - A.comp_uofs[c] : -1;
-      for (int k = 0; k < 4; ++k) if (vm[k] && row[k] >= 0) vl[row[k]].push_back((uint16_t)(i * 40 + k));
-      for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j)
-        if (mm[k * 4 + j] && row[k] >= 0 && row[j] >= 0) ml[(size_t)row[k] * cl.nc + row[j]].push_back((uint16_t)(i * 40 + 8 + k * 4 + j));
+      bool vm[NTERM], mm[NTERM * NTERM];
+      kind_mask(e.kind, vm, mm, e.nt);
+      if (e.kind == K_MOS || e.kind == K_VA) cl.nonlinear = true;
+      int row[NTERM];
+      for (int k = 0; k < NTERM; ++k) row[k] = e.term[k] >= 0 ? e.term[k] - A.comp_uofs[c] : -1;
+      for (int k = 0; k < NTERM; ++k) if (vm[k] && row[k] >= 0) vl[row[k]].push_back((uint16_t)(i * stride + k));
+      for (int k = 0; k < NTERM; ++k) for (int j = 0; j < NTERM; ++j)
+        if (mm[k * NTERM + j] && row[k] >= 0 && row[j] >= 0) ml[(size_t)row[k] * cl.nc + row[j]].push_back((uint16_t)(i * stride + gofs + k * gld + j));
     }
     cl.mat_ptr.push_back(0);
     for (auto& l : ml) { cl.mat_src.insert(cl.mat_src.end(), l.begin(), l.end()); cl.mat_ptr.push_back((int)cl.mat_src.size()); }

@@ -213,6 +213,8 @@ struct ch_circuit {
   DevBuf<double> d_rate;
   DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ, d_dumpC, d_dumpG, d_dumpF0, d_temp, d_omega, d_xac, d_psd;
   DevBuf<int> d_noise_a, d_noise_b, d_noise_h, d_acfail;
+  DevBuf<double> d_vapar;
+  std::vector<double> va_par;   // parameter blocks of the Verilog-A instances
   int Stemp = 1;
   double ac_scale = 0.0;        // eval_sources adds ac_scale*|ac| to every source value (AC right-hand side)  // (d_srcv unused: source values share d_kv)
   DevBuf<unsigned char> d_dmask, d_active;
@@ -282,12 +284,13 @@ struct ch_circuit {
     }
     block_threads = std::min(256, std::max(64, ((max_slots + 63) / 64) * 64));
     lu_variant = A.max_nc <= 8 ? 8 : (A.max_nc <= 12 ? 12 : (A.max_nc <= 16 ? 16 : (A.max_nc <= 32 ? 32 : 0)));
+    if (A.wide) lu_variant = A.max_nc <= 16 ? 16 : 0;  // wide (Verilog-A) stamp records: two instantiations only
     std::vector<int> dkind, dterm, dsrc, dhdev;
     dev_src.clear();
     { std::vector<int> slot_of(src.size(), -1);
       for (const EDev& e : A.edev) {
-        dkind.push_back(e.kind); for (int k = 0; k < 4; ++k) dterm.push_back(e.term[k]); dhdev.push_back(e.hdev);
-        int si = 0;
+        dkind.push_back(e.kind); for (int k = 0; k < NTERM; ++k) dterm.push_back(e.term[k]); dhdev.push_back(e.hdev);
+        int si = e.kind == K_VA ? dev[e.hdev].ipar[1] : 0;
         if (e.src >= 0) { if (slot_of[e.src] < 0) { slot_of[e.src] = (int)dev_src.size(); dev_src.push_back(e.src); } si = slot_of[e.src]; }
         dsrc.push_back(si);
       }
@@ -322,7 +325,7 @@ struct ch_circuit {
     lds_doubles_fixed = 0; lds_extra_bytes = 0;
     for (size_t ci = 0; ci < A.classes.size(); ++ci) {
       const CompClass& c = A.classes[ci];
-      lds_doubles_fixed = std::max(lds_doubles_fixed, (size_t)c.ndev * 40 + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 8 * (size_t)c.nc);
+      lds_doubles_fixed = std::max(lds_doubles_fixed, (size_t)c.ndev * A.stride() + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 8 * (size_t)c.nc);
       lds_extra_bytes = std::max(lds_extra_bytes, ((size_t)cms[ci].blob_ints + 64) * 4 + 16);  // blob + the block's MOS class list
     }
     return CH_OK;
@@ -377,6 +380,7 @@ struct ch_circuit {
       }
     }
     HIPCHK(d_dpar.upload(hpar, st)); HIPCHK(d_dmult.upload(hmult, st)); HIPCHK(d_gmin.upload(hg, st)); HIPCHK(d_temp.upload(htemp, st));
+    { std::vector<double> vp = va_par; if (vp.empty()) vp.push_back(0.0); HIPCHK(d_vapar.upload(vp, st)); }
     // MOS classes: instances with identical (model, geometry, overriding slots) share a column
     const int nmos = (int)A.mos_hdev.size();
     mos_cls.assign(nmos, 0);
@@ -425,6 +429,7 @@ struct ch_circuit {
         std::vector<int> seen;
         for (int d = 0; d < A.comp_ndev[k]; ++d) {
           const EDev& e = A.edev[A.comp_dofs[k] + d];
+          if (e.kind == K_VA) { dloc[A.comp_dofs[k] + d] = dev[e.hdev].ipar[0]; continue; }
           if (e.mos < 0) continue;
           const int cl = mos_cls[e.mos];
           int j = (int)(std::find(seen.begin(), seen.end(), cl) - seen.begin());
@@ -469,7 +474,7 @@ struct ch_circuit {
     a.comp_class = d_comp_class.p; a.comp_uofs = d_comp_uofs.p; a.comp_dofs = d_comp_dofs.p; a.classes = d_classes.p;
     a.blob = d_gl_ptr.p; a.dkind = d_dkind.p; a.dterm = d_dterm.p; a.dsrc = d_dsrc.p; a.dcls = d_dcls.p; a.dhdev = d_dhdev.p;
     a.dpar = d_dpar.p; a.dmult = d_dmult.p; a.mosp = d_mosp.p; a.mos_cols = cols; a.kv = d_kv.p; a.srcv = d_kv.p + (size_t)Ssrc * A.known.size(); a.dmask = d_dmask.p;
-    a.active = nullptr; a.gmin_s = d_gmin.p;
+    a.active = nullptr; a.gmin_s = d_gmin.p; a.vapar = d_vapar.p; a.temp_s = d_temp.p; a.Stemp = Stemp;
     a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = n_dev_src();
     a.n_unk = A.n_unk; a.n_mos_cls = n_cls;
     a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = host_reduce ? h_out : d_out.p;
@@ -482,6 +487,7 @@ struct ch_circuit {
     lds_bytes = (lds_doubles_fixed + A.known.size() + n_dev_src() + (size_t)max_mc * B4I_COUNT) * sizeof(double) + lds_extra_bytes;
     lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
     path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || max_mc > 64 || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
+    if (path == 2 && A.wide) { set_err("compiled Verilog-A devices need Jacobian blocks that fit one CU (no sparse-path support yet)"); return CH_ERR_UNSUPPORTED; }
     if (path == 2) {
       if (S != 1) { set_err("the sparse path (Jacobian blocks larger than one CU's LDS) handles one sample at a time"); return CH_ERR_UNSUPPORTED; }
       int rcs = build_sparse_structure();
@@ -494,6 +500,8 @@ struct ch_circuit {
       HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     HIPCHK(hipStreamSynchronize(st));
     dirty = false;
@@ -540,9 +548,9 @@ struct ch_circuit {
     std::vector<std::vector<int>> vrows(n);
     for (int d = 0; d < nd; ++d) {
       const EDev& e = A.edev[d];
-      bool vm[4], mm[16]; kind_mask(e.kind, vm, mm);
+      bool vm[NTERM], mm[NTERM * NTERM]; kind_mask(e.kind, vm, mm, e.nt);
       for (int k = 0; k < 4; ++k) if (vm[k] && e.term[k] >= 0) vrows[e.term[k]].push_back(d * 40 + k);
-      for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j) if (mm[k * 4 + j] && e.term[k] >= 0 && e.term[j] >= 0) rows[e.term[k]][e.term[j]].push_back(d * 40 + 8 + k * 4 + j);
+      for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j) if (mm[k * NTERM + j] && e.term[k] >= 0 && e.term[j] >= 0) rows[e.term[k]][e.term[j]].push_back(d * 40 + 8 + k * 4 + j);
     }
     for (int i = 0; i < n; ++i) rows[i][i];  // structural diagonal (gmin stepping, pivots)
     h_rowptr.assign(1, 0); h_colidx.clear();
@@ -694,7 +702,11 @@ struct ch_circuit {
     // kernel duration is sampled with HIP events on 1 launch in 4 (the events cost host time on every step)
     const bool timed = (n_launch & 3) == 0;
     if (timed) HIPCHK(hipEventRecord(ev0, st));
-    if (lu_variant == 8) hipLaunchKernelGGL(newton_block_kernel<8>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+    if (A.wide) {
+      if (lu_variant == 16) hipLaunchKernelGGL((newton_block_kernel<16, true>), dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+      else hipLaunchKernelGGL((newton_block_kernel<0, true>), dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+    }
+    else if (lu_variant == 8) hipLaunchKernelGGL(newton_block_kernel<8>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
     else if (lu_variant == 12) hipLaunchKernelGGL(newton_block_kernel<12>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
     else if (lu_variant == 16) hipLaunchKernelGGL(newton_block_kernel<16>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
     else if (lu_variant == 32) hipLaunchKernelGGL(newton_block_kernel<32>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
@@ -1065,9 +1077,16 @@ ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
     if (v.mult < 0) return bad("Cannot construct a ParallelInstances with non-positive multiplier");
     if ((v.kind == CH_DEV_V || v.kind == CH_DEV_I) && (v.ipar[0] < 0 || v.ipar[0] >= d->n_src)) return bad("source index out of range");
     if (v.kind == CH_DEV_MOS && (v.ipar[0] < 0 || v.ipar[0] >= d->n_model)) return bad("model index out of range");
-    if (v.kind < CH_DEV_R || v.kind > CH_DEV_MOS) return bad("unknown device kind");
+    if (v.kind < CH_DEV_R || v.kind > CH_DEV_VA) return bad("unknown device kind");
+    if (v.kind == CH_DEV_VA) {
+      if (v.ipar[0] < 0 || v.ipar[0] >= va_gen::N_MODULES) return bad("Verilog-A module id out of range (is the module compiled into this library?)");
+      const va_gen::ModuleInfo& mi = va_gen::MODULES[v.ipar[0]];
+      if (v.ipar[1] < 0 || (int64_t)v.ipar[1] + 2 * mi.n_params > d->n_va_par || !d->va_par) return bad("Verilog-A parameter block out of range");
+      v.va_nt = mi.n_nodes; v.va_qmask = mi.q_mask;
+    }
     c->dev.push_back(v);
   }
+  if (d->va_par && d->n_va_par > 0) c->va_par.assign(d->va_par, d->va_par + d->n_va_par);
   for (int i = 0; i < d->n_slot; ++i) { c->slot_kind.push_back(d->slot_kind[i]); c->slot_a.push_back(d->slot_a[i]); c->slot_b.push_back(d->slot_b[i]); }
   for (int i = 0; i < d->n_obs; ++i) { c->obs_kind.push_back(d->obs_kind[i]); c->obs_index.push_back(d->obs_index[i]); }
   c->slot_val.assign(c->slot_kind.size(), {});
@@ -1481,6 +1500,38 @@ int ch_bench_fp64(ch_ctx* ctx, int32_t iters, double* tflops_out) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
   *tflops_out = best;
   return best > 0 ? CH_OK : CH_ERR_DEVICE;
+}
+int32_t ch_va_n_modules(void) { return va_gen::N_MODULES; }
+int32_t ch_va_find(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < va_gen::N_MODULES; ++i) if (std::strcmp(va_gen::MODULES[i].name, name) == 0) return i;
+  return -1;
+}
+const char* ch_va_module_name(int32_t id) { return (id >= 0 && id < va_gen::N_MODULES) ? va_gen::MODULES[id].name : nullptr; }
+int32_t ch_va_module_info(int32_t id, int32_t* n_ports, int32_t* n_nodes, int32_t* n_params) {
+  if (id < 0 || id >= va_gen::N_MODULES) return CH_ERR_INVALID;
+  const va_gen::ModuleInfo& mi = va_gen::MODULES[id];
+  if (n_ports) *n_ports = mi.n_ports; if (n_nodes) *n_nodes = mi.n_nodes; if (n_params) *n_params = mi.n_params;
+  return CH_OK;
+}
+const char* ch_va_node_name(int32_t id, int32_t k) { return (id >= 0 && id < va_gen::N_MODULES && k >= 0 && k < va_gen::MODULES[id].n_nodes) ? va_gen::MODULES[id].node_names[k] : nullptr; }
+const char* ch_va_param_name(int32_t id, int32_t k) { return (id >= 0 && id < va_gen::N_MODULES && k >= 0 && k < va_gen::MODULES[id].n_params) ? va_gen::MODULES[id].param_names[k] : nullptr; }
+int ch_va_eval(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* st_out) {
+  if (!ctx || !par || !v || !st_out || id < 0 || id >= va_gen::N_MODULES) return CH_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  const va_gen::ModuleInfo& mi = va_gen::MODULES[id];
+  const size_t np = (size_t)std::max(1, 2 * mi.n_params);
+  double *dp = nullptr, *dv = nullptr, *ds = nullptr;
+  if (hipMalloc((void**)&dp, np * sizeof(double)) != hipSuccess || hipMalloc((void**)&dv, NTERM * sizeof(double)) != hipSuccess || hipMalloc((void**)&ds, 144 * sizeof(double)) != hipSuccess) return CH_ERR_DEVICE;
+  double vv[NTERM] = {0}; for (int k = 0; k < mi.n_nodes; ++k) vv[k] = v[k];
+  (void)hipMemcpy(dp, par, (size_t)2 * mi.n_params * sizeof(double), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dv, vv, sizeof(vv), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(va_eval_kernel, dim3(1), dim3(64), 0, ctx->stream, (int)id, (const double*)dp, (const double*)dv, temperature_k, gmin, ds);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(st_out, ds, 144 * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dp); (void)hipFree(dv); (void)hipFree(ds);
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return CH_ERR_DEVICE; }
+  return CH_OK;
 }
 const char* ch_version(void) { return "cedarhip 0.1 (gfx950; fused block Newton)"; }
 

@@ -20,6 +20,7 @@
 
 #include "ch_analysis.hpp"
 #include "ch_bsim4.hpp"
+#include "_generated/va_models.hpp"
 
 namespace chip {
 
@@ -66,6 +67,8 @@ struct NewtonArgs {
   const int* dcls_local;                     // per device: index into its block's MOS class list
   const int* comp_mc_ofs; const int* comp_mc_n; const int* mc_list;  // per block: distinct MOS classes
   const double* dpar; const double* dmult;   // [n_hdev * Spar]
+  const double* vapar;                       // parameter blocks of the compiled Verilog-A instances (dsrc[d] = offset, dcls_local[d] = module)
+  const double* temp_s; int Stemp;           // Celsius per sample ($temperature of Verilog-A modules)
   const double* mosp; long mos_cols;         // packed BSIM4 table [mos_cols][B4I_COUNT]
   const double* kv; const double* srcv;      // known-node values [Ssrc][nk], source values [Ssrc][nsrc]
   const unsigned char* dmask;                // per unknown: bit0 differential, bit1 branch current
@@ -122,16 +125,48 @@ struct EvalCtx {
   const double* dpar; const double* dmult;
   int Spar;
   double gmin;
+  const double* vapar;
+  double temp_k;
 };
 
+// stamp record layouts: narrow [I(4)|Q(4)|G(4x4)|C(4x4)] = 40 doubles; wide (a compiled Verilog-A device is
+// present) [I(8)|Q(8)|G(8x8)|C(8x8)] = 144 doubles
+template <bool WIDE> struct StampLayout {
+  static constexpr int STRIDE = WIDE ? 144 : 40, QO = WIDE ? 8 : 4, GO = WIDE ? 16 : 8, CO = WIDE ? 64 : 16, LD = WIDE ? 8 : 4;
+};
+__device__ __forceinline__ void widen_stamp(const double* t, double* st) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    st[k] = t[k]; st[8 + k] = t[4 + k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st[16 + k * 8 + j] = t[8 + k * 4 + j]; st[80 + k * 8 + j] = t[24 + k * 4 + j]; }
+  }
+}
+
 // Evaluate one lane slot of the device-evaluation phase.  slot = (local device << 2) | sub-lane.
+template <bool WIDE>
 __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int slot, const double* xl, int uofs,
                                           const double* kvl, const double* svl, const double* pl, double* stage) {
   const int dl = slot >> 2;
   const int d = dofs + dl;
-  double* st = stage + (size_t)dl * 40;
+  double* st_final = stage + (size_t)dl * StampLayout<WIDE>::STRIDE;
   const int kind = a.dkind[d];
-  const int* tm = a.dterm + 4 * d;
+  const int* tm = a.dterm + NTERM * d;
+  if (WIDE && kind == K_VA) {
+    double vv[NTERM];
+#pragma unroll
+    for (int k = 0; k < NTERM; ++k) { const int t = tm[k]; vv[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
+    const long pi = (long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0);
+    const va::Env env{a.temp_k, a.gmin};
+    va_gen::stamp(a.dcls_local[d], a.vapar + a.dsrc[d], vv, env, a.dmult[pi], st_final);
+    return;
+  }
+  double tmp40[WIDE ? 40 : 1];
+  double* st = WIDE ? tmp40 : st_final;
+  if (WIDE) {
+#pragma unroll
+    for (int j = 0; j < 40; ++j) tmp40[j] = 0.0;
+  }
   double v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { const int t = tm[k]; v[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
@@ -145,6 +180,7 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
     b4_device(P, v[0], v[1], v[2], v[3], a.gmin, o);
 #pragma unroll
     for (int j = 0; j < 40; ++j) st[j] = m * o[j];
+    if (WIDE) widen_stamp(st, st_final);
     return;
   }
   switch (kind) {
@@ -187,6 +223,7 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
       st[24 + 2] = 0.0; st[24 + 3] = 0.0; st[24 + 6] = 0.0; st[24 + 7] = 0.0;
     } break;
   }
+  if (WIDE) widen_stamp(st, st_final);
 }
 
 // ---- DPP reductions over the 16-lane rows of a wavefront (no LDS round trip, ~8 cycles a step) ----
@@ -291,8 +328,9 @@ __device__ inline bool lu_solve_lds(double* A, int lda, int nc, int lane) {
 
 // LDS layout (doubles): st[ndev*40] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq dx w qn [8*nc] | kvl[nk] svl[nsrc]
 //                       | ints: mptr[nc*nc+1] vptr[nc+1] slots[nslots] | u16: msrc[] vsrc[]
-template <int NC>
+template <int NC, bool WIDE = false>
 __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a) {
+  typedef StampLayout<WIDE> SL;
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int blk = blockIdx.x;
@@ -302,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
   const int nc = cm.nc, ndev = cm.ndev, uofs = bm.uofs, dofs = bm.dofs;
   const int lda = nc + 1;
   double* st = lds;
-  double* A = st + (size_t)ndev * 40;
+  double* A = st + (size_t)ndev * SL::STRIDE;
   double* Cm = A + (size_t)nc * lda;
   double* xl = Cm + (size_t)nc * nc;
   double* xp = xl + nc; double* Fv = xp + nc; double* Qv = Fv + nc; double* hq = Qv + nc;
@@ -396,16 +434,17 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
     const int maxit = a.mode == MODE_EVAL ? 1 : a.maxit;
     const double rate_prev = (a.mode == MODE_TRAN && !a.reset_rate) ? a.rate[blk] : 1.0;
     double rate_new = -1.0, dn_prev = 0.0;  // wave 0 only
-    const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0]};
+    const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar,
+                       WIDE ? a.temp_s[a.Stemp > 1 ? s : 0] + 273.15 : 300.15};
     for (int it = 0; it <= maxit; ++it) {
       // (1) device evaluation → staging (all waves)
-      for (int q = tid; q < cm.nslots; q += nthr) { const int sl = slots[q]; if (sl >= 0) eval_slot(ectx, s, dofs, sl, xl, uofs, kvl, svl, pl, st); }
+      for (int q = tid; q < cm.nslots; q += nthr) { const int sl = slots[q]; if (sl >= 0) eval_slot<WIDE>(ectx, s, dofs, sl, xl, uofs, kvl, svl, pl, st); }
       __syncthreads();
       CH_STAMP(1);
       // (2) gather (all waves)
       for (int e = tid; e < nc * nc; e += nthr) {
         double g = 0.0, cc = 0.0;
-        for (int p = mptr[e]; p < mptr[e + 1]; ++p) { const int o = msrc[p]; g += st[o]; cc += st[o + 16]; }
+        for (int p = mptr[e]; p < mptr[e + 1]; ++p) { const int o = msrc[p]; g += st[o]; cc += st[o + SL::CO]; }
         const int r = e / nc, col = e - r * nc;
         if (r == col && a.gshunt != 0.0 && !(a.dmask[uofs + r] & 2)) g += a.gshunt;  // node rows only
         A[r * lda + col] = g + alpha0 * cc;
@@ -413,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       }
       for (int i = tid; i < nc; i += nthr) {
         double f = 0.0, q = 0.0;
-        for (int p = vptr[i]; p < vptr[i + 1]; ++p) { const int o = vsrc[p]; f += st[o]; q += st[o + 4]; }
+        for (int p = vptr[i]; p < vptr[i + 1]; ++p) { const int o = vsrc[p]; f += st[o]; q += st[o + SL::QO]; }
         if (a.gshunt != 0.0 && !(a.dmask[uofs + i] & 2)) f += a.gshunt * xl[i];
         Qv[i] = q;
         const double F = f + alpha0 * q + hq[i];
@@ -783,6 +822,17 @@ __global__ __launch_bounds__(64) void ac_block_kernel(const AcArgs a) {
     acc = wave_sum(acc);
     if (lane == 0) a.psd_out[(long)s * a.n_freq + f] = ok ? acc : CH_NAN;
   }
+}
+
+// one compiled Verilog-A module at given node voltages (ch_va_eval: stamp-level parity entry point)
+__global__ void va_eval_kernel(int mod, const double* P, const double* v, double temp_k, double gmin, double* st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double vv[NTERM], out[144];
+  for (int k = 0; k < NTERM; ++k) vv[k] = v[k];
+  for (int k = 0; k < 144; ++k) out[k] = 0.0;
+  const va::Env env{temp_k, gmin};
+  va_gen::stamp(mod, P, vv, env, 1.0, out);
+  for (int k = 0; k < 144; ++k) st[k] = out[k];
 }
 
 // y = x - y (AC right-hand side b = F(src) - F(src + ac))

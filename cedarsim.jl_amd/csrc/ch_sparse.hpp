@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
   if (dev >= d.n_dev) return;
   const double* kvl = a.inline_vals ? nullptr : a.kv;
   const int kind = a.dkind[dev];
-  const int* tm = a.dterm + 4 * dev;
+  const int* tm = a.dterm + NTERM * dev;
   double v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {

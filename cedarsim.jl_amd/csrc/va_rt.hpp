@@ -1,0 +1,165 @@
+// va_rt.hpp — runtime of the generated Verilog-A device functions (cedarsim.jl_amd/va/codegen.py).
+// Self-contained (host and gfx950 device): forward-mode dual numbers generic over their scalar type, so a
+// module that uses ddx() is instantiated over nested duals (outer = Jacobian directions, one per device
+// node; inner = the ddx probe nodes) and gets exact second derivatives — what the reference obtains from
+// ForwardDiff.Dual{SimTag} inside DAECompiler's own derivative pass (src/vasim.jl:347-357, 392-412).
+// Math follows src/va_env.jl:35-47 (NaNMath: ln/sqrt/pow return NaN outside their domain).
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define VA_HD __host__ __device__ __forceinline__
+#define VA_HD_NOINLINE __host__ __device__
+#else
+#define VA_HD inline
+#define VA_HD_NOINLINE inline
+#endif
+
+namespace va {
+
+struct Env {
+  double temperature;  // kelvin: $temperature (src/va_env.jl:123)
+  double gmin;         // $simparam("gmin")
+};
+
+template <int N, class S>
+struct VD {
+  S v;
+  S d[N];
+  VA_HD VD() : v(0.0) { for (int i = 0; i < N; ++i) d[i] = S(0.0); }
+  VA_HD VD(double c) : v(c) { for (int i = 0; i < N; ++i) d[i] = S(0.0); }
+  VA_HD VD(int c) : v((double)c) { for (int i = 0; i < N; ++i) d[i] = S(0.0); }
+  VA_HD VD(const S& c, int) : v(c) { for (int i = 0; i < N; ++i) d[i] = S(0.0); }
+};
+
+// plain value at the bottom of any nesting
+VA_HD double val(double x) { return x; }
+VA_HD double val(int x) { return (double)x; }
+template <int N, class S> VA_HD double val(const VD<N, S>& x) { return val(x.v); }
+
+template <int N, class S> VA_HD VD<N, S> operator+(const VD<N, S>& a, const VD<N, S>& b) { VD<N, S> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N, class S> VA_HD VD<N, S> operator-(const VD<N, S>& a, const VD<N, S>& b) { VD<N, S> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N, class S> VA_HD VD<N, S> operator-(const VD<N, S>& a) { VD<N, S> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+template <int N, class S> VA_HD VD<N, S> operator*(const VD<N, S>& a, const VD<N, S>& b) { VD<N, S> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N, class S> VA_HD VD<N, S> operator/(const VD<N, S>& a, const VD<N, S>& b) {
+  VD<N, S> r; const S ib = S(1.0) / b.v; r.v = a.v * ib;
+  for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+  return r;
+}
+#define VA_MIXED(OP) \
+  template <int N, class S> VA_HD VD<N, S> operator OP(const VD<N, S>& a, double b) { return a OP VD<N, S>(b); } \
+  template <int N, class S> VA_HD VD<N, S> operator OP(double a, const VD<N, S>& b) { return VD<N, S>(a) OP b; } \
+  template <int N, class S> VA_HD VD<N, S> operator OP(const VD<N, S>& a, int b) { return a OP VD<N, S>((double)b); } \
+  template <int N, class S> VA_HD VD<N, S> operator OP(int a, const VD<N, S>& b) { return VD<N, S>((double)a) OP b; }
+VA_MIXED(+) VA_MIXED(-) VA_MIXED(*) VA_MIXED(/)
+#undef VA_MIXED
+template <int N, class S> VA_HD VD<N, S>& operator+=(VD<N, S>& a, const VD<N, S>& b) { a = a + b; return a; }
+template <int N, class S> VA_HD VD<N, S>& operator-=(VD<N, S>& a, const VD<N, S>& b) { a = a - b; return a; }
+
+// f(x) with derivative g = f'(x.v): chain rule, generic over the nesting
+template <int N, class S> VA_HD VD<N, S> chain(const VD<N, S>& x, const S& f, const S& g) { VD<N, S> r; r.v = f; for (int i = 0; i < N; ++i) r.d[i] = g * x.d[i]; return r; }
+
+VA_HD double v_exp(double x) { return ::exp(x); }
+VA_HD double v_ln(double x) { return x > 0.0 ? ::log(x) : (x == 0.0 ? -INFINITY : NAN); }
+VA_HD double v_log10(double x) { return x > 0.0 ? ::log10(x) : (x == 0.0 ? -INFINITY : NAN); }
+VA_HD double v_sqrt(double x) { return x >= 0.0 ? ::sqrt(x) : NAN; }
+VA_HD double v_sin(double x) { return ::sin(x); }
+VA_HD double v_cos(double x) { return ::cos(x); }
+VA_HD double v_tan(double x) { return ::tan(x); }
+VA_HD double v_sinh(double x) { return ::sinh(x); }
+VA_HD double v_cosh(double x) { return ::cosh(x); }
+VA_HD double v_tanh(double x) { return ::tanh(x); }
+VA_HD double v_atan(double x) { return ::atan(x); }
+VA_HD double v_asin(double x) { return (x >= -1.0 && x <= 1.0) ? ::asin(x) : NAN; }
+VA_HD double v_acos(double x) { return (x >= -1.0 && x <= 1.0) ? ::acos(x) : NAN; }
+VA_HD double v_asinh(double x) { return ::asinh(x); }
+VA_HD double v_acosh(double x) { return x >= 1.0 ? ::acosh(x) : NAN; }
+VA_HD double v_atanh(double x) { return (x > -1.0 && x < 1.0) ? ::atanh(x) : NAN; }
+VA_HD double v_abs(double x) { return ::fabs(x); }
+VA_HD int v_abs(int x) { return x < 0 ? -x : x; }
+VA_HD double v_floor(double x) { return ::floor(x); }
+VA_HD double v_ceil(double x) { return ::ceil(x); }
+VA_HD double v_limexp(double x) { return x < 80.0 ? ::exp(x) : ::exp(80.0) * (1.0 + (x - 80.0)); }
+VA_HD double v_pow(double a, double b) { return (a < 0.0 && b != ::floor(b)) ? NAN : ::pow(a, b); }
+VA_HD double v_min(double a, double b) { return a < b ? a : b; }
+VA_HD double v_max(double a, double b) { return a > b ? a : b; }
+VA_HD int v_min(int a, int b) { return a < b ? a : b; }
+VA_HD int v_max(int a, int b) { return a > b ? a : b; }
+VA_HD double v_atan2(double y, double x) { return ::atan2(y, x); }
+VA_HD double v_hypot(double a, double b) { return ::sqrt(a * a + b * b); }
+
+template <int N, class S> VA_HD VD<N, S> v_exp(const VD<N, S>& x) { const S e = v_exp(x.v); return chain(x, e, e); }
+template <int N, class S> VA_HD VD<N, S> v_ln(const VD<N, S>& x) { return chain(x, v_ln(x.v), S(1.0) / x.v); }
+template <int N, class S> VA_HD VD<N, S> v_log10(const VD<N, S>& x) { return chain(x, v_log10(x.v), S(0.43429448190325182765) / x.v); }
+template <int N, class S> VA_HD VD<N, S> v_sqrt(const VD<N, S>& x) { const S r = v_sqrt(x.v); return chain(x, r, S(0.5) / r); }
+template <int N, class S> VA_HD VD<N, S> v_sin(const VD<N, S>& x) { return chain(x, v_sin(x.v), v_cos(x.v)); }
+template <int N, class S> VA_HD VD<N, S> v_cos(const VD<N, S>& x) { return chain(x, v_cos(x.v), -v_sin(x.v)); }
+template <int N, class S> VA_HD VD<N, S> v_tan(const VD<N, S>& x) { const S t = v_tan(x.v); return chain(x, t, S(1.0) + t * t); }
+template <int N, class S> VA_HD VD<N, S> v_sinh(const VD<N, S>& x) { return chain(x, v_sinh(x.v), v_cosh(x.v)); }
+template <int N, class S> VA_HD VD<N, S> v_cosh(const VD<N, S>& x) { return chain(x, v_cosh(x.v), v_sinh(x.v)); }
+template <int N, class S> VA_HD VD<N, S> v_tanh(const VD<N, S>& x) { const S t = v_tanh(x.v); return chain(x, t, S(1.0) - t * t); }
+template <int N, class S> VA_HD VD<N, S> v_atan(const VD<N, S>& x) { return chain(x, v_atan(x.v), S(1.0) / (S(1.0) + x.v * x.v)); }
+template <int N, class S> VA_HD VD<N, S> v_asin(const VD<N, S>& x) { return chain(x, v_asin(x.v), S(1.0) / v_sqrt(S(1.0) - x.v * x.v)); }
+template <int N, class S> VA_HD VD<N, S> v_acos(const VD<N, S>& x) { return chain(x, v_acos(x.v), S(-1.0) / v_sqrt(S(1.0) - x.v * x.v)); }
+template <int N, class S> VA_HD VD<N, S> v_asinh(const VD<N, S>& x) { return chain(x, v_asinh(x.v), S(1.0) / v_sqrt(x.v * x.v + S(1.0))); }
+template <int N, class S> VA_HD VD<N, S> v_acosh(const VD<N, S>& x) { return chain(x, v_acosh(x.v), S(1.0) / v_sqrt(x.v * x.v - S(1.0))); }
+template <int N, class S> VA_HD VD<N, S> v_atanh(const VD<N, S>& x) { return chain(x, v_atanh(x.v), S(1.0) / (S(1.0) - x.v * x.v)); }
+template <int N, class S> VA_HD VD<N, S> v_abs(const VD<N, S>& x) { return val(x) < 0.0 ? -x : x; }
+template <int N, class S> VA_HD double v_floor(const VD<N, S>& x) { return ::floor(val(x)); }
+template <int N, class S> VA_HD double v_ceil(const VD<N, S>& x) { return ::ceil(val(x)); }
+template <int N, class S> VA_HD VD<N, S> v_limexp(const VD<N, S>& x) { if (val(x) < 80.0) return v_exp(x); return (x - 79.0) * ::exp(80.0); }
+template <int N, class S> VA_HD VD<N, S> v_min(const VD<N, S>& a, const VD<N, S>& b) { return val(a) < val(b) ? a : b; }
+template <int N, class S> VA_HD VD<N, S> v_max(const VD<N, S>& a, const VD<N, S>& b) { return val(a) > val(b) ? a : b; }
+template <int N, class S> VA_HD VD<N, S> v_hypot(const VD<N, S>& a, const VD<N, S>& b) { return v_sqrt(a * a + b * b); }
+template <int N, class S> VA_HD VD<N, S> v_atan2(const VD<N, S>& y, const VD<N, S>& x) {
+  VD<N, S> r; const S r2 = x.v * x.v + y.v * y.v; r.v = v_atan2(y.v, x.v);
+  for (int i = 0; i < N; ++i) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) / r2;
+  return r;
+}
+// pow: constant exponent → b·a^(b-1) with a strong zero for the exponent's tangent (src/va_env.jl:60-70)
+template <int N, class S> VA_HD VD<N, S> v_pow(const VD<N, S>& a, double b) {
+  if (b == 0.0) return VD<N, S>(1.0);
+  return chain(a, v_pow(a.v, b), S(b) * v_pow(a.v, b - 1.0));
+}
+template <int N, class S> VA_HD VD<N, S> v_pow(const VD<N, S>& a, int b) { return v_pow(a, (double)b); }
+template <int N, class S> VA_HD VD<N, S> v_pow(const VD<N, S>& a, const VD<N, S>& b) {
+  const double av = val(a), bv = val(b);
+  if (av > 0.0) return v_exp(b * v_ln(a));
+  if (av == 0.0 && bv > 0.0) return VD<N, S>(0.0);
+  return VD<N, S>(NAN);
+}
+template <int N, class S> VA_HD VD<N, S> v_pow(double a, const VD<N, S>& b) { return v_pow(VD<N, S>(a), b); }
+
+// VA real → integer: round half away from zero (LRM 4.2.1.1, src/va_env.jl:107)
+VA_HD int to_int(double x) { return (int)(x >= 0.0 ? ::floor(x + 0.5) : -::floor(-x + 0.5)); }
+VA_HD int to_int(int x) { return x; }
+template <int N, class S> VA_HD int to_int(const VD<N, S>& x) { return to_int(val(x)); }
+VA_HD bool truth(double x) { return x != 0.0; }
+VA_HD bool truth(int x) { return x != 0; }
+VA_HD bool truth(bool x) { return x; }
+template <int N, class S> VA_HD bool truth(const VD<N, S>& x) { return val(x) != 0.0; }
+
+// ddx(e, V(a)) / ddx(e, V(a,b)) on the nested type R = VD<NT, VD<ND,double>> (src/vasim.jl:392-412)
+template <int NT, int ND> VA_HD VD<NT, VD<ND, double>> ddx1(const VD<NT, VD<ND, double>>& x, int ia) {
+  VD<NT, VD<ND, double>> r; r.v = VD<ND, double>(x.v.d[ia]);
+  for (int k = 0; k < NT; ++k) r.d[k] = VD<ND, double>(x.d[k].d[ia]);
+  return r;
+}
+template <int NT, int ND> VA_HD VD<NT, VD<ND, double>> ddx2(const VD<NT, VD<ND, double>>& x, int ia, int ib) {
+  VD<NT, VD<ND, double>> r; r.v = VD<ND, double>(0.5 * (x.v.d[ia] - x.v.d[ib]));
+  for (int k = 0; k < NT; ++k) r.d[k] = VD<ND, double>(0.5 * (x.d[k].d[ia] - x.d[k].d[ib]));
+  return r;
+}
+VA_HD double ddx1(double, int) { return 0.0; }
+VA_HD double ddx2(double, int, int) { return 0.0; }
+
+// seeds: node voltage k of NT as the outer variable; with ND > 0 also the inner variable `dk` (or -1)
+template <int NT> VA_HD VD<NT, double> seed(double v, int k, int /*dk*/, VD<NT, double>*) { VD<NT, double> r(v); r.d[k] = 1.0; return r; }
+template <int NT, int ND> VA_HD VD<NT, VD<ND, double>> seed(double v, int k, int dk, VD<NT, VD<ND, double>>*) {
+  VD<NT, VD<ND, double>> r; r.v = VD<ND, double>(v); if (dk >= 0) r.v.d[dk] = 1.0;
+  r.d[k] = VD<ND, double>(1.0);
+  return r;
+}
+
+}  // namespace va

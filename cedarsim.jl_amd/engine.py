@@ -21,7 +21,8 @@ EXPORTS = [
     "ch_circuit_free", "ch_circuit_info", "ch_circuit_maps", "ch_set_samples", "ch_set_params", "ch_dc", "ch_tran",
     "ch_result_n_times", "ch_result_times", "ch_result_values", "ch_result_final_state", "ch_result_stats",
     "ch_result_status", "ch_result_free", "ch_eval", "ch_ac", "ch_noise", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
-    "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64",
+    "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64", "ch_va_n_modules", "ch_va_find", "ch_va_module_name", "ch_va_module_info",
+    "ch_va_node_name", "ch_va_param_name", "ch_va_eval",
 ]
 
 _lib = None
@@ -68,6 +69,15 @@ def load_library():
     L.ch_bsim4_param_ignored.argtypes = [C.c_char_p]
     L.ch_ac.argtypes = [vp, C.POINTER(ChDcOpts), C.c_int32, _pf64, _pf64, C.POINTER(ChStats)]
     L.ch_noise.argtypes = [vp, C.POINTER(ChDcOpts), C.c_int32, C.c_int32, C.c_int32, _pf64, _pf64, C.POINTER(ChStats)]
+    L.ch_va_find.argtypes = [C.c_char_p]
+    L.ch_va_module_name.argtypes = [C.c_int32]
+    L.ch_va_module_name.restype = C.c_char_p
+    L.ch_va_module_info.argtypes = [C.c_int32, _pi32, _pi32, _pi32]
+    L.ch_va_node_name.argtypes = [C.c_int32, C.c_int32]
+    L.ch_va_node_name.restype = C.c_char_p
+    L.ch_va_param_name.argtypes = [C.c_int32, C.c_int32]
+    L.ch_va_param_name.restype = C.c_char_p
+    L.ch_va_eval.argtypes = [vp, C.c_int32, _pf64, _pf64, C.c_double, C.c_double, _pf64]
     L.ch_version.restype = C.c_char_p
     L.ch_bench_triad.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     L.ch_bench_fp64.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
@@ -101,6 +111,17 @@ class Context:
         if rc != 0:
             raise RuntimeError("ch_bench_fp64 failed: %s" % self.last_error())
         return out.value
+
+    def va_eval(self, module_id, par_and_given, v_nodes, temperature_k=300.15, gmin=1e-12):
+        """One compiled Verilog-A module on the GPU: the 144-double wide stamp [I(8)|Q(8)|G(8x8)|C(8x8)]."""
+        p = np.ascontiguousarray(par_and_given, dtype=np.float64)
+        v = np.zeros(8)
+        v[:len(v_nodes)] = v_nodes
+        out = np.zeros(144)
+        rc = self.L.ch_va_eval(self.h, int(module_id), _p(p), _p(v), float(temperature_k), float(gmin), _p(out))
+        if rc != 0:
+            raise RuntimeError("ch_va_eval failed: %s" % self.last_error())
+        return out
 
     def triad_gbps(self, n_doubles=1 << 27, iters=5):
         """Measured STREAM-triad bandwidth of this GPU in GB/s (measurement utility)."""
@@ -139,6 +160,11 @@ class EngineCircuit:
         self.L = self.ctx.L
         self.circuit = circuit
         self._desc = circuit.to_desc()
+        for nm, (mod, _) in getattr(circuit, "va_instances", {}).items():
+            mid = circuit.dev_ipar[circuit.dev_names.index(nm)][0]
+            got = self.L.ch_va_module_name(mid)
+            if got is None or got.decode() != mod.name:
+                raise CedarError("the Verilog-A model library (lib/va_modules.json) and libcedarhip.so are out of step: rebuild both")
         self.h = self.L.ch_circuit_build(self.ctx.h, C.byref(self._desc))
         if not self.h:
             raise CedarError("ch_circuit_build failed: %s" % self.ctx.last_error())

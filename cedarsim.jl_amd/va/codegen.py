@@ -1,0 +1,587 @@
+"""Verilog-A → C++ (HIP device + host) code generator — the MI355X counterpart of `make_spice_device`
+(src/vasim.jl:649-867), which turns a parsed module into a Julia device functor.
+
+For every module one function template is emitted:
+
+    template <class R> void eval_<module>(const double* P, const R* V, const va::Env& env, R* I, R* Q)
+
+P  : parameter values in declaration order followed by the same number of "given" flags
+V  : node voltages (ports then internal nets), seeded as dual numbers by the dispatcher
+I/Q: per-node sums of the resistive currents / the charges under ddt() leaving the node through the device
+     (`I(a,b) <+ f + ddt(q)` adds f to I[a], −f to I[b], q to Q[a], −q to Q[b])
+
+plus a registry (names of modules, nodes, parameters) and `va_gen::stamp(module, …)`, which seeds the
+duals, runs the module and scatters values and derivatives into the engine's wide stamp record
+[I(8) | Q(8) | G(8×8) | C(8×8)].  The same header is compiled into libcedarhip.so (device) and into the
+test oracle (host), so a model added to the VA library is available to both after a rebuild.
+
+Typing: VA `integer` → int, VA `real` → double unless a fixed-point pass finds that the variable can
+depend on a node voltage, in which case it is the dual type R.  Analog functions are templates over one
+scalar type S, instantiated with R when any argument is dual.
+"""
+from .frontend import FLOW_ACCESS, POTENTIAL_ACCESS, VAError
+
+MAX_NODES = 8
+
+_F1 = {"exp", "ln", "sqrt", "sin", "cos", "tan", "sinh", "cosh", "tanh", "atan", "asin", "acos", "asinh", "acosh", "atanh", "abs",
+       "floor", "ceil", "limexp"}
+_F2 = {"pow", "min", "max", "atan2", "hypot"}
+_RENAME = {"log": "log10"}
+
+
+def _walk(e):
+    if isinstance(e, tuple):
+        yield e
+        for c in e:
+            yield from _walk(c)
+    elif isinstance(e, (list,)):
+        for c in e:
+            yield from _walk(c)
+    elif isinstance(e, dict):
+        for c in e.values():
+            yield from _walk(c)
+
+
+def _has_ddt(e):
+    return any(n[0] == "call" and n[1] == "ddt" for n in _walk(e) if len(n) >= 2)
+
+
+class ModuleGen:
+    def __init__(self, module):
+        self.m = module
+        if len(module.nodes) > MAX_NODES:
+            raise VAError("module %s has %d nodes; the engine's stamp record holds %d" % (module.name, len(module.nodes), MAX_NODES))
+        self.node_ix = {n: i for i, n in enumerate(module.nodes)}
+        self.param_ix = {p[0]: i for i, p in enumerate(module.params)}
+        self.param_ty = {p[0]: p[1] for p in module.params}
+        self.ddx_nodes = self._ddx_nodes()
+        self.all_vars = dict(module.vars)
+        for n in _walk(module.analog):
+            if n and n[0] == "block" and isinstance(n[2], dict):
+                self.all_vars.update(n[2])
+        self.dual = set()
+        self._infer_dual()
+        self.tmp = 0
+
+    # ---- analyses ----
+    def _ddx_nodes(self):
+        order = []
+        for n in _walk([self.m.analog] + [f.body for f in self.m.functions.values()]):
+            if len(n) >= 3 and n[0] == "call" and n[1] == "ddx":
+                probe = n[2][1]
+                if probe[0] != "call" or probe[1] not in POTENTIAL_ACCESS:
+                    raise VAError("ddx(): the second argument must be a potential probe V(a) or V(a,b)")
+                for a in probe[2]:
+                    if a[1] not in order:
+                        order.append(a[1])
+        return order
+
+    def _is_dual(self, e):
+        k = e[0]
+        if k in ("num", "str"):
+            return False
+        if k == "id":
+            return e[1] in self.dual
+        if k == "un":
+            return self._is_dual(e[2])
+        if k == "bin":
+            if e[1] in ("<", "<=", ">", ">=", "==", "!=", "&&", "||", "&", "|", "^", "<<", ">>", "%"):
+                return False
+            return self._is_dual(e[2]) or self._is_dual(e[3])
+        if k == "tern":
+            return self._is_dual(e[2]) or self._is_dual(e[3])
+        if k == "call":
+            name = e[1]
+            if name in POTENTIAL_ACCESS or name in FLOW_ACCESS or name == "ddx":
+                return True
+            if name.startswith("$") and name[1:] not in _F1 and name[1:] not in _F2 and name not in ("$limit",):
+                return False
+            if name in ("floor", "ceil", "$floor", "$ceil", "white_noise", "flicker_noise"):
+                return False
+            return any(self._is_dual(a) for a in e[2])
+        return False
+
+    def _infer_dual(self):
+        changed = True
+        while changed:
+            changed = False
+            for n in _walk(self.m.analog):
+                if not n:
+                    continue
+                if n[0] == "assign" and n[1] not in self.dual and self.all_vars.get(n[1]) == "real" and self._is_dual(n[2]):
+                    self.dual.add(n[1])
+                    changed = True
+                if n[0] == "call" and n[1] in self.m.functions:
+                    f = self.m.functions[n[1]]
+                    if any(self._is_dual(a) for a in n[2]):
+                        for (nm, kind), a in zip(f.args, n[2]):
+                            if kind in ("output", "inout") and a[0] == "id" and a[1] not in self.dual and self.all_vars.get(a[1]) == "real":
+                                self.dual.add(a[1])
+                                changed = True
+
+    # ---- expressions: returns (code, type) with type in int|real|dual ----
+    def cast(self, code, ty, to, S):
+        if ty == to:
+            return code
+        if to == "dual":
+            return "%s(%s)" % (S, code) if ty == "real" else "%s((double)(%s))" % (S, code)
+        if to == "real":
+            if ty == "int":
+                return "(double)(%s)" % code
+            return "va::val(%s)" % code
+        if to == "int":
+            return "va::to_int(%s)" % code
+        raise VAError("cast %s -> %s" % (ty, to))
+
+    @staticmethod
+    def promote(a, b):
+        return "dual" if "dual" in (a, b) else ("real" if "real" in (a, b) else "int")
+
+    def expr(self, e, ctx):
+        """ctx: dict(vars={name: type}, S=scalar type name for 'dual', infunc=bool)"""
+        k = e[0]
+        S = ctx["S"]
+        if k == "num":
+            if e[2]:
+                return str(e[1]), "int"
+            v = e[1]
+            if v != v:
+                return "NAN", "real"
+            if v in (float("inf"), float("-inf")):
+                return ("INFINITY" if v > 0 else "-INFINITY"), "real"
+            return repr(float(v)), "real"
+        if k == "id":
+            name = e[1]
+            if name in ctx["vars"]:
+                return "v_" + name, ctx["vars"][name]
+            if name in self.param_ix:
+                ty = self.param_ty[name]
+                if ty == "string":
+                    raise VAError("string parameter '%s' cannot be used in an expression" % name)
+                return "p_" + name, ("int" if ty == "integer" else "real")
+            raise VAError("undefined identifier '%s' in module %s" % (name, self.m.name))
+        if k == "str":
+            raise VAError("string in an arithmetic expression")
+        if k == "un":
+            c, t = self.expr(e[2], ctx)
+            if e[1] == "-":
+                return "(-%s)" % c, t
+            if e[1] == "!":
+                return "(va::truth(%s) ? 0 : 1)" % c, "int"
+            return "(~%s)" % self.cast(c, t, "int", S), "int"
+        if k == "bin":
+            op = e[1]
+            a, ta = self.expr(e[2], ctx)
+            b, tb = self.expr(e[3], ctx)
+            if op in ("+", "-", "*"):
+                return "(%s %s %s)" % (a, op, b), self.promote(ta, tb)
+            if op == "/":   # always real division (the reference maps `/` to Julia's `/`, src/vasim.jl:221-232)
+                t = self.promote(self.promote(ta, tb), "real")
+                return "(%s / %s)" % (self.cast(a, ta, t, S) if ta == "int" else a, self.cast(b, tb, t, S) if tb == "int" else b), t
+            if op == "**":
+                t = self.promote(self.promote(ta, tb), "real")
+                if ta == "dual" and tb != "dual":
+                    return "va::v_pow(%s, %s)" % (a, b), "dual"
+                return "va::v_pow(%s, %s)" % (self.cast(a, ta, t, S), self.cast(b, tb, t, S)), t
+            if op == "%":
+                if ta == "int" and tb == "int":
+                    return "(%s %% %s)" % (a, b), "int"
+                return "::fmod(%s, %s)" % (self.cast(a, ta, "real", S), self.cast(b, tb, "real", S)), "real"
+            if op in ("<", "<=", ">", ">=", "==", "!="):
+                av = a if ta == "int" else self.cast(a, ta, "real", S)
+                bv = b if tb == "int" else self.cast(b, tb, "real", S)
+                return "((%s %s %s) ? 1 : 0)" % (av, op, bv), "int"
+            if op in ("&&", "||"):
+                return "((va::truth(%s) %s va::truth(%s)) ? 1 : 0)" % (a, op, b), "int"
+            return "(%s %s %s)" % (self.cast(a, ta, "int", S), op, self.cast(b, tb, "int", S)), "int"
+        if k == "tern":
+            c, _ = self.expr(e[1], ctx)
+            a, ta = self.expr(e[2], ctx)
+            b, tb = self.expr(e[3], ctx)
+            t = self.promote(ta, tb)
+            return "(va::truth(%s) ? %s : %s)" % (c, self.cast(a, ta, t, S), self.cast(b, tb, t, S)), t
+        if k == "call":
+            return self.call(e, ctx)
+        raise VAError("cannot generate %r" % (e,))
+
+    def probe(self, acc, nodes, ctx):
+        if ctx.get("infunc"):
+            raise VAError("branch probes inside analog functions are not supported")
+        if acc in FLOW_ACCESS:
+            raise VAError("flow probe %s(%s) is not supported" % (acc, ",".join(nodes)))
+        if len(nodes) == 1 and nodes[0] in self.m.branches:
+            nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
+        for n in nodes:
+            if n not in self.node_ix:
+                raise VAError("unknown node '%s' in module %s" % (n, self.m.name))
+        if len(nodes) == 1:
+            return "V[%d]" % self.node_ix[nodes[0]], "dual"
+        return "(V[%d] - V[%d])" % (self.node_ix[nodes[0]], self.node_ix[nodes[1]]), "dual"
+
+    def call(self, e, ctx):
+        name, args, S = e[1], e[2], ctx["S"]
+        if name in POTENTIAL_ACCESS or name in FLOW_ACCESS:
+            return self.probe(name, [a[1] for a in args], ctx)
+        if name == "$temperature":
+            return "env.temperature", "real"
+        if name == "$vt":
+            if args:
+                c, t = self.expr(args[0], ctx)
+                return "(%s * 8.617343e-5)" % c if False else "(%s * (1.3806503e-23 / 1.602176462e-19))" % c, self.promote(t, "real")
+            return "(env.temperature * (1.3806503e-23 / 1.602176462e-19))", "real"
+        if name in ("$param_given", "$given"):
+            pn = args[0][1]
+            pn = self.m.aliases.get(pn, pn)
+            if pn not in self.param_ix:
+                raise VAError("$param_given(%s): no such parameter" % pn)
+            return "g_" + pn, "int"
+        if name == "$simparam":
+            if args[0][0] == "str" and args[0][1] == "gmin":
+                return "env.gmin", "real"
+            if len(args) > 1:
+                return self.expr(args[1], ctx)
+            raise VAError("$simparam(\"%s\") has no value" % (args[0][1],))
+        if name == "$mfactor":
+            return "1.0", "real"
+        if name == "$port_connected":
+            return "1", "int"
+        if name in ("$abstime", "$realtime"):
+            return "0.0", "real"
+        if name == "$limit":
+            return self.expr(args[0], ctx)
+        if name in ("white_noise", "flicker_noise"):
+            return "0.0", "real"
+        if name == "ddt":
+            raise VAError("ddt() is only supported as an additive (possibly scaled) term of a contribution")
+        if name == "ddx":
+            c, t = self.expr(args[0], ctx)
+            ix = [self.ddx_nodes.index(a[1]) for a in args[1][2]]
+            c = self.cast(c, t, "dual", S)
+            if len(ix) == 1:
+                return "va::ddx1(%s, %d)" % (c, ix[0]), "dual"
+            return "va::ddx2(%s, %d, %d)" % (c, ix[0], ix[1]), "dual"
+        base = name[1:] if name.startswith("$") else name
+        base = _RENAME.get(base, base)
+        if base in _F1 and (name in _F1 or name.startswith("$") or name == "log"):
+            c, t = self.expr(args[0], ctx)
+            if base in ("floor", "ceil"):
+                return "va::v_%s(%s)" % (base, self.cast(c, t, "real", S) if t == "int" else c), "real"
+            if base == "abs" and t == "int":
+                return "va::v_abs(%s)" % c, "int"
+            t2 = self.promote(t, "real")
+            return "va::v_%s(%s)" % (base, self.cast(c, t, t2, S)), t2
+        if base == "log10":
+            c, t = self.expr(args[0], ctx)
+            t2 = self.promote(t, "real")
+            return "va::v_log10(%s)" % self.cast(c, t, t2, S), t2
+        if base in _F2:
+            a, ta = self.expr(args[0], ctx)
+            b, tb = self.expr(args[1], ctx)
+            t = self.promote(ta, tb)
+            if base in ("min", "max") and t == "int":
+                return "va::v_%s(%s, %s)" % (base, a, b), "int"
+            t = self.promote(t, "real")
+            if base == "pow" and ta == "dual" and tb != "dual":
+                return "va::v_pow(%s, %s)" % (a, b), "dual"
+            return "va::v_%s(%s, %s)" % (base, self.cast(a, ta, t, S), self.cast(b, tb, t, S)), t
+        if name in self.m.functions:
+            return self.user_call(self.m.functions[name], args, ctx)
+        raise VAError("unknown function '%s' in module %s" % (name, self.m.name))
+
+    def user_call(self, f, args, ctx):
+        if len(args) != len(f.args):
+            raise VAError("function %s expects %d arguments, got %d" % (f.name, len(f.args), len(args)))
+        S = ctx["S"]
+        ev = [self.expr(a, ctx) if kind != "output" else (None, None) for (nm, kind), a in zip(f.args, args)]
+        # outputs whose target variable is dual force the dual instantiation as well
+        anydual = any(t == "dual" for c, t in ev if c is not None)
+        for (nm, kind), a in zip(f.args, args):
+            if kind in ("output", "inout") and a[0] == "id" and ctx["vars"].get(a[1]) == "dual":
+                anydual = anydual or False
+        FS = S if anydual else "double"
+        fty = "dual" if anydual else "real"
+        call_args, pre, post = [], [], []
+        has_out = any(kind != "input" for _, kind in f.args)
+        for (nm, kind), a, (c, t) in zip(f.args, args, ev):
+            aty = f.vars.get(nm, "real")
+            if kind == "input":
+                call_args.append(self.cast(c, t, "int" if aty == "integer" else fty, S))
+                continue
+            if a[0] != "id" or a[1] not in ctx["vars"]:
+                raise VAError("output argument of %s must be a variable" % f.name)
+            self.tmp += 1
+            tn = "o%d_" % self.tmp
+            tt = "int" if aty == "integer" else FS
+            init = ""
+            if kind == "inout":
+                init = " = " + self.cast(c, t, "int" if aty == "integer" else fty, S)
+            pre.append("%s %s%s;" % (tt, tn, init))
+            call_args.append(tn)
+            vty = ctx["vars"][a[1]]
+            post.append("v_%s = %s;" % (a[1], self.cast(tn, "int" if aty == "integer" else fty, vty, S)))
+        rty = "int" if f.rtype == "integer" else fty
+        callc = "f_%s<%s>(%s)" % (f.name, FS, ", ".join(["env"] + call_args))
+        if not has_out:
+            return callc, rty
+        rt = "int" if rty == "int" else FS
+        return "([&]() -> %s { %s %s r_ = %s; %s return r_; }())" % (rt, " ".join(pre), rt, callc, " ".join(post)), rty
+
+    # ---- statements ----
+    def split_ddt(self, e):
+        """(resistive AST or None, reactive AST or None)"""
+        k = e[0]
+        if k == "call" and e[1] == "ddt":
+            return None, e[2][0]
+        if not _has_ddt(e):
+            return e, None
+        if k == "bin" and e[1] in ("+", "-"):
+            ar, aq = self.split_ddt(e[2])
+            br, bq = self.split_ddt(e[3])
+
+            def comb(x, y):
+                if x is None and y is None:
+                    return None
+                if y is None:
+                    return x
+                if x is None:
+                    return y if e[1] == "+" else ("un", "-", y)
+                return ("bin", e[1], x, y)
+            return comb(ar, br), comb(aq, bq)
+        if k == "un" and e[1] == "-":
+            r, q = self.split_ddt(e[2])
+            return (None if r is None else ("un", "-", r)), (None if q is None else ("un", "-", q))
+        if k == "bin" and e[1] == "*":
+            for x, y, left in ((e[2], e[3], True), (e[3], e[2], False)):
+                if _has_ddt(x) and not _has_ddt(y):
+                    r, q = self.split_ddt(x)
+
+                    def mul(z):
+                        return None if z is None else (("bin", "*", z, y) if left else ("bin", "*", y, z))
+                    return mul(r), mul(q)
+        if k == "bin" and e[1] == "/" and _has_ddt(e[2]) and not _has_ddt(e[3]):
+            r, q = self.split_ddt(e[2])
+            return (None if r is None else ("bin", "/", r, e[3])), (None if q is None else ("bin", "/", q, e[3]))
+        if k == "tern":
+            ar, aq = self.split_ddt(e[2])
+            br, bq = self.split_ddt(e[3])
+            zero = ("num", 0.0, False)
+            r = None if ar is None and br is None else ("tern", e[1], ar or zero, br or zero)
+            q = None if aq is None and bq is None else ("tern", e[1], aq or zero, bq or zero)
+            return r, q
+        raise VAError("ddt() must appear as an additive (possibly scaled) term of a contribution")
+
+    def stmt(self, st, ctx, ind):
+        k = st[0]
+        pad = "  " * ind
+        S = ctx["S"]
+        if k == "assign":
+            name = st[1]
+            if name not in ctx["vars"]:
+                raise VAError("assignment to undeclared variable '%s' in module %s" % (name, self.m.name))
+            c, t = self.expr(st[2], ctx)
+            return ["%sv_%s = %s;" % (pad, name, self.cast(c, t, ctx["vars"][name], S))]
+        if k == "contrib":
+            if ctx.get("infunc"):
+                raise VAError("contribution inside an analog function")
+            acc, nodes = st[1], st[2]
+            if len(nodes) == 1 and nodes[0] in self.m.branches:
+                nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
+            if acc in POTENTIAL_ACCESS:
+                # V(a,b) <+ 0: node collapse, resolved structurally on the host (the two nodes are merged before
+                # the circuit reaches the engine); any other voltage contribution is rejected there.
+                return ["%s/* V(%s) <+ ...: node collapse handled at circuit build */" % (pad, ",".join(nodes))]
+            if acc not in FLOW_ACCESS:
+                raise VAError("unknown access function %s" % acc)
+            r, q = self.split_ddt(st[3])
+            a = self.node_ix[nodes[0]]
+            b = self.node_ix[nodes[1]] if len(nodes) > 1 else None
+            out = []
+            for ast, arr in ((r, "I"), (q, "Q")):
+                if ast is None:
+                    continue
+                c, t = self.expr(ast, ctx)
+                out.append("%s{ const %s c_ = %s; %s[%d] += c_;%s }" % (pad, S, self.cast(c, t, "dual", S), arr, a,
+                                                                         (" %s[%d] -= c_;" % (arr, b)) if b is not None else ""))
+            return out
+        if k == "if":
+            c, _ = self.expr(st[1], ctx)
+            out = ["%sif (va::truth(%s)) {" % (pad, c)] + self.stmt(st[2], ctx, ind + 1)
+            if st[3] is not None:
+                out += ["%s} else {" % pad] + self.stmt(st[3], ctx, ind + 1)
+            return out + ["%s}" % pad]
+        if k == "block":
+            out = ["%s{" % pad]
+            if st[2]:
+                ctx = dict(ctx, vars=dict(ctx["vars"]))
+                for nm, ty in st[2].items():
+                    t = "int" if ty == "integer" else ("dual" if (ctx.get("infunc") or nm in self.dual) else "real")
+                    ctx["vars"][nm] = t
+                    out.append("%s  %s v_%s = 0;" % (pad, {"int": "int", "real": "double", "dual": S}[t], nm))
+            for s in st[3]:
+                out += self.stmt(s, ctx, ind + 1)
+            return out + ["%s}" % pad]
+        if k == "case":
+            c, t = self.expr(st[1], ctx)
+            self.tmp += 1
+            sv = "sw%d_" % self.tmp
+            out = ["%s{ const double %s = %s;" % (pad, sv, self.cast(c, t, "real", S) if t != "real" else c)]
+            first, default = True, None
+            for conds, body in st[2]:
+                if conds is None:
+                    default = body
+                    continue
+                tests = []
+                for cd in conds:
+                    cc, ct = self.expr(cd, ctx)
+                    tests.append("%s == %s" % (sv, self.cast(cc, ct, "real", S) if ct != "real" else cc))
+                out.append("%s%sif (%s) {" % (pad, "" if first else "} else ", " || ".join(tests)))
+                out += self.stmt(body, ctx, ind + 1)
+                first = False
+            if default is not None:
+                out.append("%s%s{" % (pad, "" if first else "} else "))
+                out += self.stmt(default, ctx, ind + 1)
+                first = False
+            if not first:
+                out.append("%s}" % pad)
+            return out + ["%s}" % pad]
+        if k == "for":
+            init = self.stmt(st[1], ctx, 0)[0]
+            c, _ = self.expr(st[2], ctx)
+            upd = self.stmt(st[3], ctx, 0)[0].rstrip(";")
+            return ["%sfor (%s va::truth(%s); %s) {" % (pad, init, c, upd)] + self.stmt(st[4], ctx, ind + 1) + ["%s}" % pad]
+        if k == "while":
+            c, _ = self.expr(st[1], ctx)
+            return ["%swhile (va::truth(%s)) {" % (pad, c)] + self.stmt(st[2], ctx, ind + 1) + ["%s}" % pad]
+        if k == "repeat":
+            c, t = self.expr(st[1], ctx)
+            self.tmp += 1
+            return ["%sfor (int r%d_ = 0, n%d_ = %s; r%d_ < n%d_; ++r%d_) {" % (pad, self.tmp, self.tmp, self.cast(c, t, "int", S), self.tmp, self.tmp, self.tmp)] + \
+                self.stmt(st[2], ctx, ind + 1) + ["%s}" % pad]
+        if k == "event":
+            return self.stmt(st[1], ctx, ind)
+        if k in ("task", "null"):
+            return []
+        raise VAError("cannot generate statement %r" % (st,))
+
+    def q_mask(self):
+        """Bit k set: node k receives a ddt() contribution somewhere in the analog block."""
+        mask = 0
+        for n in _walk(self.m.analog):
+            if n and n[0] == "contrib" and n[1] in FLOW_ACCESS and _has_ddt(n[3]):
+                nodes = n[2]
+                if len(nodes) == 1 and nodes[0] in self.m.branches:
+                    nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
+                for nd in nodes:
+                    mask |= 1 << self.node_ix[nd]
+        return mask
+
+    # ---- top level ----
+    def function(self, f):
+        targs = []
+        for nm, kind in f.args:
+            ty = "int" if f.vars.get(nm) == "integer" else "S"
+            targs.append("%s%s v_%s" % (ty, "&" if kind != "input" else "", nm))
+        rt = "int" if f.rtype == "integer" else "S"
+        out = ["template <class S> VA_HD %s f_%s(%s) {" % (rt, f.name, ", ".join(["const va::Env& env"] + targs))]
+        argn = {nm for nm, _ in f.args}
+        vars_ = {}
+        for nm, ty in f.vars.items():
+            t = "int" if ty == "integer" else "dual"
+            vars_[nm] = t
+            if nm not in argn:
+                out.append("  %s v_%s = 0;" % ("int" if t == "int" else "S", nm))
+        out.append("  (void)env;")
+        ctx = {"vars": vars_, "S": "S", "infunc": True}
+        out += self.stmt(f.body, ctx, 1)
+        out.append("  return v_%s;" % f.name)
+        out.append("}")
+        return out
+
+    def generate(self):
+        m = self.m
+        out = ["// ---- module %s: %d ports, %d internal nodes, %d parameters ----" % (m.name, len(m.ports), len(m.internal), len(m.params))]
+        out.append("namespace m_%s {" % m.name)
+        for f in m.functions.values():
+            out += self.function(f)
+        out.append("template <class R> VA_HD_NOINLINE void eval(const double* P, const R* V, const va::Env& env, R* I, R* Q) {")
+        np_ = len(m.params)
+        used = set()
+        for n in _walk([m.analog]):
+            if n and n[0] == "id":
+                used.add(n[1])
+            if n and n[0] == "call" and n[1] in ("$param_given", "$given"):
+                used.add("?" + m.aliases.get(n[2][0][1], n[2][0][1]))
+        for i, (nm, ty, _, _) in enumerate(m.params):
+            if ty == "string":
+                continue
+            if nm in used:
+                out.append("  const %s p_%s = %sP[%d];" % ("int" if ty == "integer" else "double", nm, "(int)" if ty == "integer" else "", i))
+            if "?" + nm in used:
+                out.append("  const int g_%s = P[%d] != 0.0 ? 1 : 0;" % (nm, np_ + i))
+        vars_ = {}
+        for nm, ty in m.vars.items():
+            if ty == "string":
+                continue
+            t = "int" if ty == "integer" else ("dual" if nm in self.dual else "real")
+            vars_[nm] = t
+            out.append("  %s v_%s = 0;" % ({"int": "int", "real": "double", "dual": "R"}[t], nm))
+        out.append("  (void)env; (void)V; (void)P;")
+        ctx = {"vars": vars_, "S": "R"}
+        for st in m.analog:
+            out += self.stmt(st, ctx, 1)
+        out.append("}")
+        out.append("}  // namespace m_%s" % m.name)
+        return out
+
+
+def generate_header(modules, source_tag=""):
+    """C++ header text for a list of parsed modules (module id = position in the list)."""
+    gens = [ModuleGen(m) for m in modules]
+    out = ["// GENERATED by cedarsim.jl_amd/va/codegen.py — do not edit.  %s" % source_tag,
+           "#pragma once", '#include "../va_rt.hpp"', "", "namespace va_gen {", ""]
+    for g in gens:
+        out += g.generate()
+        out.append("")
+    out.append("struct ModuleInfo { const char* name; int n_ports, n_nodes, n_params; unsigned q_mask; const char* const* node_names; const char* const* param_names; };")
+    for g in gens:
+        m = g.m
+        out.append("static const char* const nodes_%s[] = {%s};" % (m.name, ", ".join('"%s"' % n for n in m.nodes) or '""'))
+        out.append("static const char* const params_%s[] = {%s};" % (m.name, ", ".join('"%s"' % p[0] for p in m.params) or '""'))
+    out.append("static const int N_MODULES = %d;" % len(gens))
+    out.append("static const ModuleInfo MODULES[] = {")
+    for g in gens:
+        m = g.m
+        out.append('  {"%s", %d, %d, %d, %du, nodes_%s, params_%s},' % (m.name, len(m.ports), len(m.nodes), len(m.params), g.q_mask(), m.name, m.name))
+    if not gens:
+        out.append('  {"", 0, 0, 0, 0u, nullptr, nullptr},')
+    out.append("};")
+    out.append("")
+    out.append("// Seeds the duals, evaluates module `mod` and scatters into the wide stamp record")
+    out.append("// st = [I(8) | Q(8) | G(8x8) | C(8x8)], every entry scaled by the multiplicity m.")
+    out.append("template <int NT, class R> VA_HD void scatter(const R* I, const R* Q, double m, double* st) {")
+    out.append("  for (int k = 0; k < NT; ++k) {")
+    out.append("    st[k] = m * va::val(I[k]); st[8 + k] = m * va::val(Q[k]);")
+    out.append("    for (int j = 0; j < NT; ++j) { st[16 + k * 8 + j] = m * va::val(I[k].d[j]); st[80 + k * 8 + j] = m * va::val(Q[k].d[j]); }")
+    out.append("  }")
+    out.append("}")
+    out.append("VA_HD_NOINLINE void stamp(int mod, const double* P, const double* v, const va::Env& env, double m, double* st) {")
+    out.append("  switch (mod) {")
+    for i, g in enumerate(gens):
+        mo = g.m
+        nt, nd = len(mo.nodes), len(g.ddx_nodes)
+        R = "va::VD<%d, double>" % nt if nd == 0 else "va::VD<%d, va::VD<%d, double>>" % (nt, nd)
+        out.append("    case %d: {" % i)
+        out.append("      typedef %s R;" % R)
+        out.append("      R V[%d], I[%d], Q[%d];" % (nt, nt, nt))
+        for k, node in enumerate(mo.nodes):
+            dk = g.ddx_nodes.index(node) if node in g.ddx_nodes else -1
+            out.append("      V[%d] = va::seed(v[%d], %d, %d, (R*)nullptr);" % (k, k, k, dk))
+        out.append("      m_%s::eval<R>(P, V, env, I, Q);" % mo.name)
+        out.append("      scatter<%d, R>(I, Q, m, st);" % nt)
+        out.append("    } break;")
+    out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
+    out.append("")
+    out.append("}  // namespace va_gen")
+    return "\n".join(out) + "\n"

@@ -50,10 +50,14 @@ enum {
   CH_DEV_I = 5,    /* CurrentSource    simpledevices.jl:327-339 ipar[0]=source                */
   CH_DEV_VCVS = 6, /* vcvs             simpledevices.jl:347-356 par[0]=gain  (branch)         */
   CH_DEV_VCCS = 7, /* vccs             simpledevices.jl:364-373 par[0]=gain                   */
-  CH_DEV_MOS = 8   /* BSIM4 functor (VA-generated in the reference, vasim.jl:853-867):
+  CH_DEV_MOS = 8,  /* BSIM4 functor (VA-generated in the reference, vasim.jl:853-867):
                       nodes d,g,s,b ; ipar[0]=model ; par = {w,l,nf,as,ad,ps,pd,-}            */
+  CH_DEV_VA = 9    /* compiled Verilog-A module (device functor of make_spice_device, vasim.jl:649-867):
+                      nodes = ports then internal nets (the caller allocates the internal nets as
+                      circuit nodes) ; ipar[0] = module id (ch_va_find) ; ipar[1] = offset of the
+                      instance's parameter block in ch_desc.va_par                              */
 };
-#define CH_DEV_NNODE 4
+#define CH_DEV_NNODE 8
 #define CH_DEV_NPAR 8
 #define CH_DEV_NIPAR 2
 
@@ -128,6 +132,10 @@ typedef struct ch_desc {
    * in src/simpledevices.jl:293,332), or NULL when no source has one.  A voltage source with ac != 0 keeps
    * its node and branch unknowns (it is never folded into a known node). */
   const double* src_ac;     /* [n_src] or NULL */
+  /* parameter blocks of the CH_DEV_VA instances: per instance 2*n_params doubles — the module's parameters in
+   * declaration order (defaults already applied, integers as doubles) followed by the $param_given flags */
+  int64_t n_va_par;
+  const double* va_par;     /* [n_va_par] or NULL */
 } ch_desc;
 
 /* Statistics — the fields CedarSim accumulates from NLStats/DEStats (src/dcop.jl:63-67,134-139) */
@@ -272,6 +280,20 @@ int ch_ac(ch_circuit*, const ch_dc_opts*, int32_t n_freq, const double* freqs_hz
  * current); psd_out[n_samples][n_freq] in V²/Hz (A²/Hz), computed with one adjoint solve per frequency. ---- */
 int ch_noise(ch_circuit*, const ch_dc_opts*, int32_t out_kind, int32_t out_index, int32_t n_freq, const double* freqs_hz,
              double* psd_out, ch_stats* stats);
+
+/* ---- compiled Verilog-A modules.  Replaces: the device functors `make_spice_device` generates from a
+ * parsed module (src/vasim.jl:649-867).  Modules are compiled ahead of time into the library by
+ * cedarsim.jl_amd/va (front-end + code generator) — the counterpart of the reference's precompiled model
+ * packages (src/ModelLoader.jl).  ch_va_eval evaluates one module instance on the GPU at given node voltages:
+ * st[144] = [I(8) | Q(8) | dI/dV (8x8) | dQ/dV (8x8)] (stamp-level parity entry point, like ch_mos_eval). ---- */
+int32_t ch_va_n_modules(void);
+int32_t ch_va_find(const char* module_name);                                  /* id or -1 */
+const char* ch_va_module_name(int32_t id);
+int32_t ch_va_module_info(int32_t id, int32_t* n_ports, int32_t* n_nodes, int32_t* n_params);
+const char* ch_va_node_name(int32_t id, int32_t k);
+const char* ch_va_param_name(int32_t id, int32_t k);
+int ch_va_eval(ch_ctx*, int32_t id, const double* par_and_given, const double* v_nodes, double temperature_k, double gmin,
+               double* st_out);
 
 /* ---- library/kernel introspection ---- */
 const char* ch_version(void);

@@ -37,6 +37,9 @@
 #include "../include/cedarhip.h"
 #include "oracle_bsim4.hpp"
 #include "oracle_dual.hpp"
+// compiled Verilog-A modules: the generated device functions (host instantiation) — shared with the engine by
+// construction; their independent check is the Python AST interpreter (tests/test_va_compiler.py)
+#include "../cedarsim.jl_amd/csrc/_generated/va_models.hpp"
 
 namespace oracle {
 
@@ -158,6 +161,7 @@ struct Circuit {
   std::vector<int> obs_kind, obs_index;
   std::vector<B4Size> mos_size;
   std::vector<int> mos_dev;  // device index of each MOS
+  std::vector<double> va_par; // parameter blocks of the Verilog-A instances
   bool sizes_dirty = true;
   std::string err;
 
@@ -244,6 +248,20 @@ static void evaluate(Circuit& c, const double* x, double t, int mode, Eval& e) {
         double i = gain * (V(cc) - V(dd));
         addF(a, m * i); addF(b, -m * i);
         addG(ra, cc - 1, m * gain); addG(ra, dd - 1, -m * gain); addG(rb, cc - 1, -m * gain); addG(rb, dd - 1, m * gain);
+      } break;
+      case CH_DEV_VA: {
+        const int mod = d.ipar[0];
+        const int nt = va_gen::MODULES[mod].n_nodes;
+        double vv[8] = {0}, st[144];
+        for (int k = 0; k < nt; ++k) vv[k] = V(d.node[k]);
+        for (int k = 0; k < 144; ++k) st[k] = 0.0;
+        const va::Env env{c.temp + 273.15, c.gmin};
+        va_gen::stamp(mod, c.va_par.data() + d.ipar[1], vv, env, m, st);
+        for (int k = 0; k < nt; ++k) {
+          addF(d.node[k], st[k]);
+          addQ(d.node[k], st[8 + k]);
+          for (int j = 0; j < nt; ++j) { addG(d.node[k] - 1, d.node[j] - 1, st[16 + k * 8 + j]); addC(d.node[k] - 1, d.node[j] - 1, st[80 + k * 8 + j]); }
+        }
       } break;
       case CH_DEV_MOS: {
         typedef Dual<4> D4;
@@ -437,6 +455,7 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
     if (d.kind == CH_DEV_C) { mark(d.node[0]); mark(d.node[1]); }
     else if (d.kind == CH_DEV_L) dmask[c.n_nodes + d.branch] = 1;
     else if (d.kind == CH_DEV_MOS) for (int k = 0; k < 4; ++k) mark(d.node[k]);
+    else if (d.kind == CH_DEV_VA) { const va_gen::ModuleInfo& mi = va_gen::MODULES[d.ipar[0]]; for (int k = 0; k < mi.n_nodes; ++k) if (mi.q_mask & (1u << k)) mark(d.node[k]); }
   }
 
   std::vector<double> bps;
@@ -689,6 +708,7 @@ void* oracle_build(const ch_desc* d) {
     if (v.kind == CH_DEV_MOS) { v.mos = (int)c->mos_dev.size(); c->mos_dev.push_back(i); }
     c->dev.push_back(v);
   }
+  if (d->va_par && d->n_va_par > 0) c->va_par.assign(d->va_par, d->va_par + d->n_va_par);
   c->mos_size.resize(c->mos_dev.size());
   c->n = c->n_nodes + c->n_branch;
   for (int i = 0; i < d->n_slot; ++i) { c->slot_kind.push_back(d->slot_kind[i]); c->slot_a.push_back(d->slot_a[i]); c->slot_b.push_back(d->slot_b[i]); }
@@ -778,6 +798,19 @@ int oracle_noise(void* h, const ch_dc_opts* o, int out_mna, int n_freq, const do
   }
   return CH_OK;
 }
+
+// one compiled Verilog-A module at given node voltages (host instantiation of the generated code)
+int oracle_va_eval(int mod, const double* par, const double* v, double temperature_k, double gmin, double* st) {
+  if (mod < 0 || mod >= va_gen::N_MODULES) return CH_ERR_INVALID;
+  double vv[8] = {0};
+  for (int k = 0; k < va_gen::MODULES[mod].n_nodes; ++k) vv[k] = v[k];
+  for (int k = 0; k < 144; ++k) st[k] = 0.0;
+  const va::Env env{temperature_k, gmin};
+  va_gen::stamp(mod, par, vv, env, 1.0, st);
+  return CH_OK;
+}
+int oracle_va_n_modules(void) { return va_gen::N_MODULES; }
+const char* oracle_va_module_name(int i) { return (i >= 0 && i < va_gen::N_MODULES) ? va_gen::MODULES[i].name : nullptr; }
 
 void* oracle_tran(void* h, double t0, double t1, const ch_tran_opts* o) {
   Circuit* c = (Circuit*)h;
