@@ -242,13 +242,13 @@ def ac(circuit, abstol=1e-10, maxiters=200, n_restarts=10, seed=10, ctx=None):
     ckt = _prepare(circuit, None)
     if not any(ckt.source_ac):
         raise CedarError("AC analysis needs at least one source with an `ac` magnitude")
-    return ACSolution(ckt, EngineCircuit(ckt, ctx), dc_opts(abstol=abstol, maxiters=maxiters, n_restarts=n_restarts, seed=seed))
+    return ACSolution(ckt, EngineCircuit(ckt, ctx, small_signal=True), dc_opts(abstol=abstol, maxiters=maxiters, n_restarts=n_restarts, seed=seed))
 
 
 def noise(circuit, abstol=1e-10, maxiters=200, n_restarts=10, seed=10, ctx=None):
     """noise!(circ): resistor thermal noise referred to an output with `.psd(sym, ωs)`."""
     ckt = _prepare(circuit, None)
-    return NoiseSolution(ckt, EngineCircuit(ckt, ctx), dc_opts(abstol=abstol, maxiters=maxiters, n_restarts=n_restarts, seed=seed))
+    return NoiseSolution(ckt, EngineCircuit(ckt, ctx, small_signal=True), dc_opts(abstol=abstol, maxiters=maxiters, n_restarts=n_restarts, seed=seed))
 
 
 class CircuitSweep:

@@ -360,7 +360,7 @@ class Circuit:
         return self.n_nodes + self.branch_devices.index(i)
 
     # -- flatten --
-    def to_desc(self):
+    def to_desc(self, small_signal=True):
         keep = {}
 
         def arr(key, data, dtype):
@@ -404,7 +404,9 @@ class Circuit:
         d.n_obs = len(self.obs)
         d.obs_kind = arr("o0", [0 if o[0] == "v" else 1 for o in self.obs], np.int32)
         d.obs_index = arr("o1", [o[1] for o in self.obs], np.int32)
-        d.src_ac = arr("sa", self.source_ac, np.float64) if any(self.source_ac) else None
+        # AC magnitudes travel only for small-signal analyses: an AC-driven voltage source keeps its node and branch as
+        # unknowns, which would needlessly couple the blocks of a DC/transient run (e.g. an inverter array on one input)
+        d.src_ac = arr("sa", self.source_ac, np.float64) if (small_signal and any(self.source_ac)) else None
         d.n_va_par = len(self.va_par)
         d.va_par = arr("vp", self.va_par, np.float64) if self.va_par else None
         d._keep = keep

@@ -155,11 +155,12 @@ def default_context(device_id=None):
 class EngineCircuit:
     """A circuit resident on the GPU: structure analysed once, parameters per sample."""
 
-    def __init__(self, circuit, ctx=None):
+    def __init__(self, circuit, ctx=None, small_signal=False):
+        """small_signal=True keeps the sources' AC magnitudes (needed by .ac(); .noise() works either way)."""
         self.ctx = ctx or default_context()
         self.L = self.ctx.L
         self.circuit = circuit
-        self._desc = circuit.to_desc()
+        self._desc = circuit.to_desc(small_signal=small_signal)
         for nm, (mod, _) in getattr(circuit, "va_instances", {}).items():
             mid = circuit.dev_ipar[circuit.dev_names.index(nm)][0]
             got = self.L.ch_va_module_name(mid)

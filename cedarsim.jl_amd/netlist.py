@@ -200,6 +200,12 @@ class ParsedNetlist:
         self.tran = None        # (tstep, tstop)
         self.warnings = []
 
+    def add_spectre_models(self, text):
+        """Register the `model` cards of a Spectre-language file (e.g. the ASAP7 `7nm_TT.scs` the reference's parser
+        tests hold) so that SPICE instance lines can name them."""
+        for name, (master, params) in parse_spectre_models(text).items():
+            self.models.setdefault(name, []).append((name, master, params))
+
     # -- SimSpec --
     def _spec(self, overrides):
         temp, gmin, scale = 27.0, 1e-12, 1.0
@@ -392,7 +398,7 @@ class ParsedNetlist:
             mod = None
             if has_module(mtype):
                 mod = mtype
-            elif mtype in ("bsimcmg107", "bsimcmg_va") and has_module("bsimcmg"):
+            elif mtype in ("bsimcmg107", "bsimcmg_va", "bsimcmg") and has_module("bsimcmg"):
                 mod = "bsimcmg"
             elif mtype in ("nmos", "pmos") and int(params.get("level", 0)) in self._VA_LEVELS and has_module(self._VA_LEVELS[int(params["level"])]):
                 mod = self._VA_LEVELS[int(params["level"])]
@@ -400,9 +406,13 @@ class ParsedNetlist:
                 return None
             card = {k: v for k, v in params.items() if k not in ("level", "version") or mod != "bsimcmg"}
             card.pop("level", None)
-            if mtype in ("nmos", "pmos") and mod in self._VA_TYPE_PARAM:
+            if mod in self._VA_TYPE_PARAM:   # TYPE/DEVTYPE from nmos|pmos or type=n|p (src/spectre.jl:632-643)
                 pn, mp = self._VA_TYPE_PARAM[mod]
-                card.setdefault(pn, mp[mtype])
+                ty = card.pop("type", None)
+                if mtype in ("nmos", "pmos"):
+                    card.setdefault(pn, mp[mtype])
+                elif ty in ("n", "p"):
+                    card.setdefault(pn, mp["nmos" if ty == "n" else "pmos"])
             return mod, card
         if base not in self.subckts and has_module(base):
             return base, {}
@@ -469,6 +479,31 @@ class ParsedNetlist:
                 dc = val(t)
                 i += 1
         return dc, tran, ac
+
+
+def parse_spectre_models(text):
+    """`model <name> <master> key=value ...` statements of a Spectre-language card file (`+` continuations, `//`
+    comments; everything else is ignored).  Returns {name: (master, {param: value})} with lower-case keys; values
+    are numbers where they parse (magnitude suffixes as in src/spectre.jl:402-415) and strings otherwise."""
+    models, cur = {}, None
+    for raw in text.splitlines():
+        line = raw.split("//")[0].strip()
+        if not line:
+            continue
+        if line.lower().startswith("model "):
+            toks = line.split()
+            cur = {}
+            models[toks[1].lower()] = (toks[2].lower(), cur)
+            line = " ".join(toks[3:])
+        elif line.startswith("+") and cur is not None:
+            line = line[1:]
+        else:
+            cur = None
+            continue
+        for k, v in re.findall(r"([A-Za-z_]\w*)\s*=\s*(\S+)", line):
+            num = parse_number(v)
+            cur[k.lower()] = v.lower() if num is None else num
+    return models
 
 
 def parse_spice(text, include_dirs=(), lib_resolver=None, _into=None, _section=None):

@@ -120,17 +120,13 @@ def m_exp(x):
     return _chain(x, _safe(math.exp, lambda v: True), m_exp)
 
 
-def m_ln(x):
-    return _chain(x, _safe(math.log, lambda v: v > 0) if True else None, lambda v: 1.0 / v) if True else None
-
-
 def _ln_scalar(v):
     if v > 0:
         return math.log(v)
     return -math.inf if v == 0 else math.nan
 
 
-def m_ln(x):  # noqa: F811
+def m_ln(x):
     return _chain(x, _ln_scalar, lambda v: 1.0 / v)
 
 
@@ -289,8 +285,11 @@ class _Frame:
 class Interp:
     """One module instance: parameters resolved, then `evaluate(V)` any number of times."""
 
-    def __init__(self, module, params=None, temperature_c=27.0, gmin=1e-12):
+    def __init__(self, module, params=None, temperature_c=27.0, gmin=1e-12, strict_ranges=False):
         self.m = module
+        # the reference does not enforce `from` / `exclude` (make_spice_device keeps only the defaults, src/vasim.jl:702-720):
+        # violations are recorded as warnings unless strict_ranges is set
+        self.strict_ranges, self.warnings = strict_ranges, []
         self.temperature = temperature_c + 273.15
         self.gmin = gmin
         self.node_ix = {n: i for i, n in enumerate(module.nodes)}
@@ -321,10 +320,15 @@ class Interp:
                     lo, hi = val(self.ev(lo, _Frame({}))), val(self.ev(hi, _Frame({})))
                     inside = (v > lo if lo_open else v >= lo) and (v < hi if hi_open else v <= hi)
                     if (kind == "from" and not inside) or (kind == "exclude" and inside):
-                        raise VAError("parameter %s = %r of %s is outside its allowed range" % (nm, v, m.name))
+                        self._range_violation("parameter %s = %r of %s is outside its allowed range" % (nm, v, m.name))
                 elif kind == "exclude" and v == val(self.ev(r, _Frame({}))):
-                    raise VAError("parameter %s = %r of %s is an excluded value" % (nm, v, m.name))
+                    self._range_violation("parameter %s = %r of %s is an excluded value" % (nm, v, m.name))
         return vals, given
+
+    def _range_violation(self, msg):
+        if self.strict_ranges:
+            raise VAError(msg)
+        self.warnings.append(msg)
 
     @staticmethod
     def _find_ddx(module):

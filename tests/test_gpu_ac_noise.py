@@ -82,7 +82,7 @@ def test_ac_nonlinear_amplifier_matches_oracle(E, O):
     ckt.observe_all_nodes()
     f = acdec(5, 1e2, 1e10)
     rc_o, xo = O(ckt).ac(f, dc_opts(abstol=1e-12))
-    rc, xe, st = E(ckt).ac(f, dc_opts(abstol=1e-12))
+    rc, xe, st = E(ckt, small_signal=True).ac(f, dc_opts(abstol=1e-12))
     assert rc == 0 and rc_o == 0
     xe = xe[0]
     gain = np.abs(xe[:, ckt._n("o") - 1])
@@ -118,7 +118,7 @@ def test_ac_current_source_and_batched_samples(E, O):
     c.C("c1", "a", 0, 1e-9)
     c.observe_node("a")
     slot = c.slot("r1", "r")
-    eng = E(c)
+    eng = E(c, small_signal=True)
     rs = np.linspace(500.0, 4000.0, 8)
     eng.set_samples(8)
     eng.set_params([slot], [list(rs)])

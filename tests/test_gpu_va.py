@@ -196,3 +196,33 @@ def test_bsimcmg_inverter_runs_and_matches_oracle(E, O):
     assert rc_o == 0
     v_o = v_o if v_o.ndim == 3 else v_o[:, :, None]
     assert np.allclose(v[:, :, 0], v_o[:, :, 0], rtol=0, atol=1e-4 * 1.0)   # 1e-4 of the 1 V swing
+
+
+def test_config5_bsimcmg_asap7_inverter_array(E, O):
+    """128 BSIM-CMG inverters (256 instances) with the ASAP7 TT cards the reference's parser
+    tests hold (SpectreNetlistParser.jl/test/examples/7nm_TT.scs → tests/golden/asap7_7nm_TT.scs) and the deck of
+    test/bsimcmg/inverter_cmg_cedar.cir (VDD = 1, SIN(0.5 0.01 1e7), 4e-7 s, abstol = reltol = 1e-7 as in
+    test/bsimcmg/inverter.jl:20).  The reference asserts `retcode == Success`; here also tile 0 == oracle and
+    identical tiles give identical waveforms."""
+    import os
+    import time
+    from cedarsim_jl_amd.workloads import CMG_TSPAN, cmg_inverter_array
+    if "bsimcmg" not in load_modules()[1]:
+        pytest.skip("bsimcmg was not in the model library build")
+    cards = open(os.path.join(os.path.dirname(__file__), "golden", "asap7_7nm_TT.scs")).read()
+    ts = np.linspace(0, 4e-7, 81)
+    opts = lambda: tran_opts(abstol=1e-7, reltol=1e-7, saveat=ts, dc=dc_opts(abstol=1e-10, tran_mode=1))  # noqa: E731
+    c = cmg_inverter_array(128, cards, observe="q")
+    eng = E(c)
+    info = eng.info()
+    assert info["n_mos"] == 0 and info["n_components"] == 128 and info["max_component"] == 5
+    t0 = time.perf_counter()
+    rc, t, v, xf, st = eng.tran(CMG_TSPAN[0], CMG_TSPAN[1], opts())
+    wall = time.perf_counter() - t0
+    assert rc == 0                                                     # ReturnCode.Success
+    assert np.abs(v[:, :, 0] - v[0:1, :, 0]).max() < 1e-12             # identical tiles
+    rc_o, t_o, v_o, _, st_o = O(cmg_inverter_array(1, cards, observe="q")).tran(CMG_TSPAN[0], CMG_TSPAN[1], opts())
+    v_o = v_o if v_o.ndim == 3 else v_o[:, :, None]
+    assert rc_o == 0
+    assert np.allclose(v[0, :, 0], v_o[0, :, 0], rtol=0, atol=1e-4)
+    print("config5: 128 inverters, %d accepted / %d rejected steps, %.3f s wall, %d block iterations" % (st["naccept"], st["nreject"], wall, st["n_block_iters"]))

@@ -84,10 +84,11 @@ def test_function_output_arguments_and_param_given():
 def test_parameter_ranges():
     _, mod = find_module("va_resistor")
     with pytest.raises(VAError):
-        Interp(mod, {"R": -1.0})
+        Interp(mod, {"R": -1.0}, strict_ranges=True)
     _, nl = find_module("va_nlvcr")
     with pytest.raises(VAError):
-        Interp(nl, {"R": 0.0})
+        Interp(nl, {"R": 0.0}, strict_ranges=True)
+    assert Interp(nl, {"R": 0.0}).warnings   # the reference does not enforce ranges: recorded, not raised
 
 
 def test_ddx_matches_reference_test_and_has_second_derivatives():
