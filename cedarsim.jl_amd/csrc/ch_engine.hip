@@ -213,6 +213,7 @@ struct ch_circuit {
   DevBuf<double> d_rate;
   DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ, d_dumpC, d_dumpG, d_dumpF0, d_temp, d_omega, d_xac, d_psd;
   DevBuf<int> d_noise_a, d_noise_b, d_noise_h, d_acfail;
+  DevBuf<double> d_noise_pwr, d_noise_exp;
   DevBuf<double> d_vapar;
   std::vector<double> va_par;   // parameter blocks of the Verilog-A instances
   int Stemp = 1;
@@ -1379,22 +1380,34 @@ int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_i
   }
   const int comp = (int)(std::upper_bound(A.comp_uofs.begin(), A.comp_uofs.end(), u_out) - A.comp_uofs.begin()) - 1;
   const int uofs = A.comp_uofs[comp], ncb = A.comp_nc[comp];
-  std::vector<int> na, nb, nh;
-  for (int d = 0; d < A.comp_ndev[comp]; ++d) {
-    const EDev& e = A.edev[A.comp_dofs[comp] + d];
-    if (e.kind != K_R) continue;
-    auto loc = [&](int t) { return (t >= uofs && t < uofs + ncb) ? t - uofs : -1; };
-    na.push_back(loc(e.term[0])); nb.push_back(loc(e.term[1])); nh.push_back(e.hdev);
-  }
   g_arena = &c->arena;
   rc = upload_omega(c, n_freq, freqs_hz); if (rc != CH_OK) return rc;
-  if (c->d_noise_a.upload(na, c->ctx->stream) != hipSuccess || c->d_noise_b.upload(nb, c->ctx->stream) != hipSuccess || c->d_noise_h.upload(nh, c->ctx->stream) != hipSuccess ||
+  // noise table of the output block at the operating point (device side)
+  const int ndev_b = A.comp_ndev[comp], n_tab = ndev_b * va::MAX_NOISE;
+  if (c->d_noise_a.alloc((size_t)S * n_tab) != hipSuccess || c->d_noise_b.alloc((size_t)S * n_tab) != hipSuccess ||
+      c->d_noise_pwr.alloc((size_t)S * n_tab) != hipSuccess || c->d_noise_exp.alloc((size_t)S * n_tab) != hipSuccess ||
       c->d_psd.alloc((size_t)S * n_freq) != hipSuccess) return CH_ERR_DEVICE;
+  {
+    NewtonArgs na0 = c->base;
+    rc = c->set_sources(na0, 0.0, o->tran_mode ? 2 : 0); if (rc != CH_OK) return rc;
+    if (na0.inline_vals) {  // the table kernel reads the known-node values from the device buffer
+      std::memcpy(c->h_stage, na0.vals_inline, (size_t)(na0.nk + na0.nsrc) * sizeof(double));
+      if (hipMemcpyAsync(c->d_kv.p, c->h_stage, (size_t)(na0.nk + na0.nsrc) * sizeof(double), hipMemcpyHostToDevice, c->ctx->stream) != hipSuccess) return CH_ERR_DEVICE;
+    }
+    NoiseTabArgs t; std::memset(&t, 0, sizeof(t));
+    t.dkind = c->d_dkind.p; t.dterm = c->d_dterm.p; t.dsrc = c->d_dsrc.p; t.dcls_local = c->d_dcls_local.p; t.dhdev = c->d_dhdev.p;
+    t.dpar = c->d_dpar.p; t.dmult = c->d_dmult.p; t.vapar = c->d_vapar.p; t.temp_s = c->d_temp.p; t.gmin_s = c->d_gmin.p;
+    t.X = c->d_X.p; t.kv = c->d_kv.p;  // slot 0 holds the operating point
+    t.Spar = c->Spar; t.Stemp = c->Stemp; t.Sgmin = c->Sgmin; t.Ssrc = c->Ssrc; t.nk = (int)A.known.size(); t.S = S; t.n_unk = A.n_unk;
+    t.dofs = A.comp_dofs[comp]; t.ndev = ndev_b; t.uofs = uofs; t.nc = ncb;
+    t.na = c->d_noise_a.p; t.nb = c->d_noise_b.p; t.pwr = c->d_noise_pwr.p; t.ex = c->d_noise_exp.p;
+    hipLaunchKernelGGL(noise_table_kernel, dim3((ndev_b * S + 63) / 64), dim3(64), 0, c->ctx->stream, t);
+  }
   AcArgs a; std::memset(&a, 0, sizeof(a));
   a.bmeta = c->d_bmeta.p; a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = nullptr; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = A.n_comp;
-  a.omega = c->d_omega.p; a.noise = 1; a.comp_out = comp; a.row_out = u_out - uofs; a.n_noise = (int)na.size();
-  a.noise_a = c->d_noise_a.p; a.noise_b = c->d_noise_b.p; a.noise_hdev = c->d_noise_h.p; a.dpar = c->d_dpar.p; a.dmult = c->d_dmult.p; a.Spar = c->Spar;
-  a.temp_s = c->d_temp.p; a.Stemp = c->Stemp; a.psd_out = c->d_psd.p; a.fail = c->d_acfail.p;
+  a.omega = c->d_omega.p; a.noise = 1; a.comp_out = comp; a.row_out = u_out - uofs; a.n_noise = n_tab;
+  a.noise_a = c->d_noise_a.p; a.noise_b = c->d_noise_b.p; a.noise_pwr = c->d_noise_pwr.p; a.noise_exp = c->d_noise_exp.p;
+  a.psd_out = c->d_psd.p; a.fail = c->d_acfail.p;
   const size_t lds = (size_t)2 * ds * (ds + 1) * sizeof(double);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ac_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(ac_block_kernel, dim3(n_freq, S), dim3(64), lds, c->ctx->stream, a);

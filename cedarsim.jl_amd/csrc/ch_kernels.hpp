@@ -733,11 +733,9 @@ struct AcArgs {
   double* x_out;                                      // AC: [S][n_freq][n_unk][2]
   // noise (adjoint) mode
   int noise, comp_out, row_out;                       // block and block-local row of the output unknown
-  int n_noise;                                        // thermal-noise resistors of the output block
-  const int* noise_a; const int* noise_b;             // block-local unknown of each terminal or -1 (known node)
-  const int* noise_hdev;                              // host device index (resistance / multiplicity lookup)
-  const double* dpar; const double* dmult; int Spar;
-  const double* temp_s; int Stemp;                    // Celsius per sample
+  int n_noise;                                        // entries of the noise table per sample (unused entries: pwr = 0)
+  const int* noise_a; const int* noise_b;             // [S][n_noise] block-local unknown of each terminal or -1 (known node)
+  const double* noise_pwr; const double* noise_exp;   // [S][n_noise] power at the operating point, flicker exponent (0 = white)
   double* psd_out;                                    // [S][n_freq]
   int* fail;                                          // set to 1 when a factorisation breaks down
 };
@@ -809,18 +807,59 @@ __global__ __launch_bounds__(64) void ac_block_kernel(const AcArgs a) {
     double* xo = a.x_out + (((long)s * a.n_freq + f) * a.n_unk + bm.uofs) * 2;
     for (int i = lane; i < nc; i += 64) { xo[2 * i] = ok ? Ar[i * lda + nc] : CH_NAN; xo[2 * i + 1] = ok ? Ai[i * lda + nc] : CH_NAN; }
   } else {
-    // output PSD = Σ_k |y_a - y_b|² · 4kT·m/R  (white_noise(dscope, 4kT/res, :thermal), src/simpledevices.jl:72-76)
-    const double T = a.temp_s[a.Stemp > 1 ? s : 0] + 273.15;
+    // output PSD = Σ_k |y_a - y_b|² · pwr_k / f^exp_k  (PSD(dss, ωs, pwr, exp), src/ac.jl:286-298)
+    const double fhz = w * 0.15915494309189535;
     double acc = 0.0;
     for (int k = lane; k < a.n_noise; k += 64) {
-      const int na = a.noise_a[k], nb = a.noise_b[k];
+      const long e = (long)s * a.n_noise + k;
+      const double pw = a.noise_pwr[e];
+      if (pw == 0.0) continue;
+      const int na = a.noise_a[e], nb = a.noise_b[e];
       const double yr = (na >= 0 ? Ar[na * lda + nc] : 0.0) - (nb >= 0 ? Ar[nb * lda + nc] : 0.0);
       const double yi = (na >= 0 ? Ai[na * lda + nc] : 0.0) - (nb >= 0 ? Ai[nb * lda + nc] : 0.0);
-      const long pi = (long)a.noise_hdev[k] * a.Spar + (a.Spar > 1 ? s : 0);
-      acc += (yr * yr + yi * yi) * 4.0 * 1.380649e-23 * T * a.dmult[pi] / a.dpar[pi];
+      const double ex = a.noise_exp[e];
+      acc += (yr * yr + yi * yi) * (ex == 0.0 ? pw : pw / pow(fhz, ex));
     }
     acc = wave_sum(acc);
     if (lane == 0) a.psd_out[(long)s * a.n_freq + f] = ok ? acc : CH_NAN;
+  }
+}
+
+// Noise sources of the output block at the DC operating point (slot `x_slot` of the state ring): resistors
+// (white_noise(dscope, 4kT/res, :thermal), src/simpledevices.jl:72-76) and the white/flicker sources of compiled
+// Verilog-A modules.  One thread per (device of the block, sample); every device owns va::MAX_NOISE table entries.
+struct NoiseTabArgs {
+  const int* dkind; const int* dterm; const int* dsrc; const int* dcls_local; const int* dhdev;
+  const double* dpar; const double* dmult; const double* vapar; const double* temp_s; const double* gmin_s;
+  const double* X; const double* kv;   // state (slot already applied) [S][n_unk]; known-node values [Ssrc][nk]
+  int Spar, Stemp, Sgmin, Ssrc, nk, S, n_unk, dofs, ndev, uofs, nc;
+  int* na; int* nb; double* pwr; double* ex;
+};
+__global__ void noise_table_kernel(const NoiseTabArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.ndev * a.S) return;
+  const int dl = i % a.ndev, s = i / a.ndev, d = a.dofs + dl;
+  const long base = ((long)s * a.ndev + dl) * va::MAX_NOISE;
+  for (int k = 0; k < va::MAX_NOISE; ++k) { a.na[base + k] = -1; a.nb[base + k] = -1; a.pwr[base + k] = 0.0; a.ex[base + k] = 0.0; }
+  const int kind = a.dkind[d];
+  const int* tm = a.dterm + NTERM * d;
+  auto loc = [&](int t) { return (t >= a.uofs && t < a.uofs + a.nc) ? t - a.uofs : -1; };
+  const long pi = (long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0);
+  const double T = a.temp_s[a.Stemp > 1 ? s : 0] + 273.15;
+  if (kind == K_R) {
+    a.na[base] = loc(tm[0]); a.nb[base] = loc(tm[1]);
+    a.pwr[base] = 4.0 * 1.380649e-23 * T * a.dmult[pi] / a.dpar[pi];
+  } else if (kind == K_VA) {
+    double vv[NTERM];
+    for (int k = 0; k < NTERM; ++k) { const int t = tm[k]; vv[k] = t >= 0 ? a.X[(long)s * a.n_unk + t] : a.kv[(long)(a.Ssrc > 1 ? s : 0) * a.nk + (-t - 1)]; }
+    va::NoiseRec rec[va::MAX_NOISE];
+    const va::Env env{T, a.gmin_s[a.Sgmin > 1 ? s : 0]};
+    const int n = va_gen::noise(a.dcls_local[d], a.vapar + a.dsrc[d], vv, env, rec);
+    for (int k = 0; k < n && k < va::MAX_NOISE; ++k) {
+      a.na[base + k] = rec[k].a >= 0 ? loc(tm[rec[k].a]) : -1;
+      a.nb[base + k] = rec[k].b >= 0 ? loc(tm[rec[k].b]) : -1;
+      a.pwr[base + k] = a.dmult[pi] * rec[k].pwr; a.ex[base + k] = rec[k].ex;
+    }
   }
 }
 

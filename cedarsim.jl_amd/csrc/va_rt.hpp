@@ -23,6 +23,12 @@ struct Env {
   double gmin;         // $simparam("gmin")
 };
 
+constexpr int MAX_NOISE = 16;  // noise sources one module instance may report
+struct NoiseRec {
+  int a, b;        // module node indices of the branch (b = -1: to ground)
+  double pwr, ex;  // white: pwr [A²/Hz]; flicker: pwr / f^ex
+};
+
 template <int N, class S>
 struct VD {
   S v;

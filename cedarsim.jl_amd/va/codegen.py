@@ -214,9 +214,10 @@ class ModuleGen:
         for n in nodes:
             if n not in self.node_ix:
                 raise VAError("unknown node '%s' in module %s" % (n, self.m.name))
+        ty = "real" if ctx.get("noise") else "dual"
         if len(nodes) == 1:
-            return "V[%d]" % self.node_ix[nodes[0]], "dual"
-        return "(V[%d] - V[%d])" % (self.node_ix[nodes[0]], self.node_ix[nodes[1]]), "dual"
+            return "V[%d]" % self.node_ix[nodes[0]], ty
+        return "(V[%d] - V[%d])" % (self.node_ix[nodes[0]], self.node_ix[nodes[1]]), ty
 
     def call(self, e, ctx):
         name, args, S = e[1], e[2], ctx["S"]
@@ -255,6 +256,8 @@ class ModuleGen:
             raise VAError("ddt() is only supported as an additive (possibly scaled) term of a contribution")
         if name == "ddx":
             c, t = self.expr(args[0], ctx)
+            if ctx.get("noise"):
+                raise VAError("ddx() in a module with noise sources is not supported by the noise pass")
             ix = [self.ddx_nodes.index(a[1]) for a in args[1][2]]
             c = self.cast(c, t, "dual", S)
             if len(ix) == 1:
@@ -392,6 +395,22 @@ class ModuleGen:
                 return ["%s/* V(%s) <+ ...: node collapse handled at circuit build */" % (pad, ",".join(nodes))]
             if acc not in FLOW_ACCESS:
                 raise VAError("unknown access function %s" % acc)
+            rhs = st[3]
+            is_noise = rhs[0] == "call" and rhs[1] in ("white_noise", "flicker_noise")
+            if ctx.get("noise"):
+                # noise pass: `I(a,b) <+ white_noise(pwr, name)` / `flicker_noise(pwr, exp, name)` become records
+                # (src/va_env.jl:92-101: the power is an observable, the source an epsilon of the linearisation)
+                if not is_noise:
+                    return []
+                nargs = [x for x in rhs[2] if x[0] != "str"]
+                pc, pt = self.expr(nargs[0], ctx)
+                ec, et = (self.expr(nargs[1], ctx) if rhs[1] == "flicker_noise" else ("0.0", "real"))
+                a = self.node_ix[nodes[0]]
+                b = self.node_ix[nodes[1]] if len(nodes) > 1 else -1
+                return ["%sif (n_ < va::MAX_NOISE) { out[n_].a = %d; out[n_].b = %d; out[n_].pwr = %s; out[n_].ex = %s; ++n_; }" %
+                        (pad, a, b, self.cast(pc, pt, "real", S), self.cast(ec, et, "real", S))]
+            if is_noise:
+                return []
             r, q = self.split_ddt(st[3])
             a = self.node_ix[nodes[0]]
             b = self.node_ix[nodes[1]] if len(nodes) > 1 else None
@@ -530,6 +549,24 @@ class ModuleGen:
         for st in m.analog:
             out += self.stmt(st, ctx, 1)
         out.append("}")
+        # noise pass: same statements over plain doubles, contributions replaced by noise records
+        self.has_noise = any(n and n[0] == "call" and n[1] in ("white_noise", "flicker_noise") for n in _walk(m.analog))
+        if self.has_noise:
+            body_start = next(i for i, l in enumerate(out) if l.startswith("template <class R> VA_HD_NOINLINE void eval("))
+            decls = [l for l in out[body_start + 1:] if l.startswith("  const ") or (l.startswith("  ") and " v_" in l and l.rstrip().endswith("= 0;") and not l.startswith("   "))]
+            out.append("VA_HD_NOINLINE int noise(const double* P, const double* V, const va::Env& env, va::NoiseRec* out) {")
+            out.append("  typedef double R; int n_ = 0;")
+            out += [l.replace(" R v_", " double v_") for l in decls]
+            out.append("  (void)env; (void)V; (void)P;")
+            nctx = {"vars": {k: ("real" if t == "dual" else t) for k, t in vars_.items()}, "S": "double", "noise": True}
+            self.dual_saved, self.dual = self.dual, set()
+            try:
+                for st in m.analog:
+                    out += self.stmt(st, nctx, 1)
+            finally:
+                self.dual = self.dual_saved
+            out.append("  return n_;")
+            out.append("}")
         out.append("}  // namespace m_%s" % m.name)
         return out
 
@@ -580,6 +617,16 @@ def generate_header(modules, source_tag=""):
         out.append("      scatter<%d, R>(I, Q, m, st);" % nt)
         out.append("    } break;")
     out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
+    out.append("")
+    out.append("// noise sources of module `mod` at node voltages v: records (node a, node b or -1, power, flicker exponent)")
+    out.append("VA_HD_NOINLINE int noise(int mod, const double* P, const double* v, const va::Env& env, va::NoiseRec* out) {")
+    out.append("  switch (mod) {")
+    for i, g in enumerate(gens):
+        if getattr(g, "has_noise", False):
+            out.append("    case %d: return m_%s::noise(P, v, env, out);" % (i, g.m.name))
+    out.append("    default: return 0;")
     out.append("  }")
     out.append("}")
     out.append("")

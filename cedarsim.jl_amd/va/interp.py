@@ -597,6 +597,13 @@ class Interp:
                     raise VAError("voltage contributions other than V(a,b) <+ 0 (node collapse) are not supported")
                 self.contribs.append(("V", tuple(nodes), "collapse"))
                 return
+            if st[3][0] == "call" and st[3][1] in ("white_noise", "flicker_noise"):
+                args = st[3][2]
+                nargs = args[:-1] if (args and args[-1][0] == "str") else args
+                vals = [val(self.ev(a, fr)) for a in nargs]
+                self.noise.append({"kind": st[3][1], "nodes": tuple(nodes), "pwr": vals[0], "exp": vals[1] if st[3][1] == "flicker_noise" else 0.0,
+                                   "name": args[-1][1] if (args and args[-1][0] == "str") else ""})
+                return
             r, q = self.split_ddt(st[3], fr)
             a = self.node_ix[nodes[0]]
             b = self.node_ix[nodes[1]] if len(nodes) > 1 else None

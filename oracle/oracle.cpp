@@ -781,22 +781,49 @@ int oracle_noise(void* h, const ch_dc_opts* o, int out_mna, int n_freq, const do
   if (out_mna < 0 || out_mna >= n) return CH_ERR_INVALID;
   Eval e; evaluate(*c, x.data(), 0.0, o->tran_mode ? 2 : 0, e);
   const double kB = 1.380649e-23, T = c->temp + 273.15;
+  // noise sources at the operating point: (node a, node b) as circuit nodes (0 = ground), power, flicker exponent
+  struct Src { int a, b; double pwr, ex; };
+  std::vector<Src> srcs;
+  for (const Device& d : c->dev) {
+    if (d.kind == CH_DEV_R) srcs.push_back({d.node[0], d.node[1], 4.0 * kB * T * d.mult / d.par[0], 0.0});
+    else if (d.kind == CH_DEV_VA) {
+      double vv[8] = {0};
+      const int nt = va_gen::MODULES[d.ipar[0]].n_nodes;
+      for (int k = 0; k < nt; ++k) vv[k] = d.node[k] ? x[d.node[k] - 1] : 0.0;
+      va::NoiseRec rec[va::MAX_NOISE];
+      const va::Env env{T, c->gmin};
+      const int nn = va_gen::noise(d.ipar[0], c->va_par.data() + d.ipar[1], vv, env, rec);
+      for (int k = 0; k < nn; ++k) srcs.push_back({d.node[rec[k].a], rec[k].b >= 0 ? d.node[rec[k].b] : 0, d.mult * rec[k].pwr, rec[k].ex});
+    }
+  }
   for (int f = 0; f < n_freq; ++f) {
     const double w = 6.283185307179586 * freqs_hz[f];
     double acc = 0.0;
-    for (const Device& d : c->dev) {
-      if (d.kind != CH_DEV_R) continue;
+    for (const Src& sr : srcs) {
+      if (sr.pwr == 0.0) continue;
       std::vector<cplx> A((size_t)n * n), r(n, cplx(0.0));
       for (size_t k = 0; k < A.size(); ++k) A[k] = cplx(e.G[k], w * e.C[k]);
       // unit noise current from node a to node b through the source: leaves a (F_a += 1), enters b
-      if (d.node[0]) r[d.node[0] - 1] -= 1.0;
-      if (d.node[1]) r[d.node[1] - 1] += 1.0;
+      if (sr.a) r[sr.a - 1] -= 1.0;
+      if (sr.b) r[sr.b - 1] += 1.0;
       if (!csolve(A, n, r)) { c->err = "singular small-signal matrix"; return CH_ERR_SINGULAR; }
-      acc += std::norm(r[out_mna]) * 4.0 * kB * T * d.mult / d.par[0];
+      acc += std::norm(r[out_mna]) * (sr.ex == 0.0 ? sr.pwr : sr.pwr / std::pow(freqs_hz[f], sr.ex));
     }
     psd_out[f] = acc;
   }
   return CH_OK;
+}
+
+// noise records of one compiled module at given node voltages: out[4*k..] = (a, b, pwr, exp); returns the count
+int oracle_va_noise(int mod, const double* par, const double* v, double temperature_k, double gmin, double* out) {
+  if (mod < 0 || mod >= va_gen::N_MODULES) return -1;
+  double vv[8] = {0};
+  for (int k = 0; k < va_gen::MODULES[mod].n_nodes; ++k) vv[k] = v[k];
+  va::NoiseRec rec[va::MAX_NOISE];
+  const va::Env env{temperature_k, gmin};
+  const int n = va_gen::noise(mod, par, vv, env, rec);
+  for (int k = 0; k < n; ++k) { out[4 * k] = rec[k].a; out[4 * k + 1] = rec[k].b; out[4 * k + 2] = rec[k].pwr; out[4 * k + 3] = rec[k].ex; }
+  return n;
 }
 
 // one compiled Verilog-A module at given node voltages (host instantiation of the generated code)

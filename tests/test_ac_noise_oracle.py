@@ -78,3 +78,23 @@ def test_oracle_noise_matches_analytic_and_ngspice():
     assert np.allclose(apsd, ng, rtol=1e-6)                   # :147 (pins the fixture itself)
     assert np.allclose(np.sqrt(psd), apsd, rtol=1e-6)         # :148
     assert np.allclose(np.sqrt(psd), ng, rtol=1e-6)
+
+
+def test_bsimcmg_inverter_noise_matches_reference_ngspice_table():
+    """test/ac.jl:155-237: output noise at node q of the ASAP7 BSIM-CMG inverter against the 61-point ngspice table
+    (rtol 1e-6 in the reference).  This pins the compiled BSIM-CMG 107 device arithmetic — operating point, ∂i/∂v,
+    ∂q/∂v and the thermal / flicker / shot noise powers — against an independent simulator."""
+    from cedarsim_jl_amd import dc_opts
+    from cedarsim_jl_amd.va.registry import load_modules
+    from cedarsim_jl_amd.workloads import cmg_inverter_array
+    if "bsimcmg" not in load_modules()[1]:
+        import pytest
+        pytest.skip("bsimcmg was not in the model library build")
+    gold = json.load(open(os.path.join(HERE, "golden", "ac_bsimcmg_inverter_noise_ngspice.json")))
+    f = np.array([r[0] for r in gold["rows"]])
+    ng = np.array([r[1] for r in gold["rows"]])
+    assert np.allclose(f, acdec(5, 1e3, 1e15), rtol=1e-8)
+    c = cmg_inverter_array(1, open(os.path.join(HERE, "golden", "asap7_7nm_TT.scs")).read())
+    rc, psd = Oracle(c).noise(c._n("q") - 1, f, dc_opts(abstol=1e-12))
+    assert rc == 0
+    assert np.allclose(np.sqrt(psd), ng, rtol=1e-6)

@@ -143,3 +143,43 @@ def test_ac_requires_a_source_and_small_blocks():
     c.R("r1", "a", 0, 1.0)
     with pytest.raises(CedarError):
         ac(c)
+
+
+def test_bsimcmg_inverter_noise_matches_ngspice_table_on_the_gpu(E, O):
+    """test/ac.jl:155-237 through ch_noise: compiled BSIM-CMG 107 + ASAP7 TT cards, output noise at node q against the
+    reference's 61-point ngspice table at the reference's own tolerance (rtol 1e-6)."""
+    from cedarsim_jl_amd.va.registry import load_modules
+    from cedarsim_jl_amd.workloads import cmg_inverter_array
+    if "bsimcmg" not in load_modules()[1]:
+        pytest.skip("bsimcmg was not in the model library build")
+    gold = json.load(open(os.path.join(HERE, "golden", "ac_bsimcmg_inverter_noise_ngspice.json")))
+    f = np.array([r[0] for r in gold["rows"]])
+    ng = np.array([r[1] for r in gold["rows"]])
+    c = cmg_inverter_array(1, open(os.path.join(HERE, "golden", "asap7_7nm_TT.scs")).read())
+    rc, psd, st = E(c).noise(0, c._n("q"), f, dc_opts(abstol=1e-12))
+    assert rc == 0
+    assert np.allclose(np.sqrt(psd[0]), ng, rtol=1e-6)
+    rc_o, po = O(c).noise(c._n("q") - 1, f, dc_opts(abstol=1e-12))
+    assert rc_o == 0 and np.allclose(psd[0], po, rtol=1e-8)
+    # the AC transfer of the same stage: engine == oracle
+    rc, xe, st = E(c, small_signal=True).ac(f[:40], dc_opts(abstol=1e-12))
+    rc_o, xo = O(c).ac(f[:40], dc_opts(abstol=1e-12))
+    assert rc == 0 and rc_o == 0
+    assert np.allclose(xe[0][:, c._n("q") - 1], xo[:, c._n("q") - 1], rtol=1e-7)
+    assert np.abs(xe[0][0, c._n("q") - 1]) > 3.0      # an inverter biased at its switching point has gain
+
+
+def test_va_noise_sources_white_and_flicker(E):
+    """Compiled module with white_noise + flicker_noise: V²/Hz at the node of a current-biased noisy resistor."""
+    c = Circuit()
+    c.temp = 50.0
+    c.I("ib", 0, "a", dc=1e-3)
+    c.VA("r1", "va_noisy_resistor", ["a", 0], {"R": 2e3, "KF": 1e-10, "AF": 2.0, "EF": 1.2}, m=2.0)
+    c.observe_node("a")
+    f = acdec(4, 1.0, 1e6)
+    rc, psd, st = E(c).noise(0, c._n("a"), f)
+    assert rc == 0
+    k, T, R = 1.3806503e-23, 50.0 + 273.15, 2e3          # the module uses `P_K of constants.vams
+    i_each = 0.5e-3                                       # two parallel instances share the bias
+    s_i = 2.0 * (4 * k * T / R + 1e-10 * i_each ** 2 / f ** 1.2)
+    assert np.allclose(psd[0], s_i * (R / 2.0) ** 2, rtol=1e-10)

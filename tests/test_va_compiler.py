@@ -187,3 +187,25 @@ v1 a 0 0.7
     assert "x1.ai" in c.node_names
     with pytest.raises(Exception):
         parse_spice("* t\nx1 a 0 no_such_module r=1\nv1 a 0 1\n").build()
+
+
+def test_generated_noise_records_match_interpreter():
+    import ctypes as C
+    pd = C.POINTER(C.c_double)
+    cases = [("va_noisy_resistor", {"R": 2e3, "KF": 1e-12, "AF": 1.5, "EF": 0.9}, {"p": 0.7, "n": -0.1})]
+    if "bsimcmg" in load_modules()[1]:
+        cases.append(("bsimcmg", {"DEVTYPE": 1, "L": 2.1e-8, "NFIN": 2, "IGCMOD": 1, "IGBMOD": 1}, {"d": 0.6, "g": 0.7, "s": 0.0, "e": 0.0, "di": 0.599, "si": 0.001}))
+    for name, params, vb in cases:
+        mid, mod = find_module(name)
+        it = Interp(mod, params, temperature_c=30.0)
+        it.evaluate(vb)
+        P = np.array([float(it.params[p[0]]) if p[1] != "string" else 0.0 for p in mod.params] + [1.0 if p[0] in it.given else 0.0 for p in mod.params] + [0.0])
+        v = np.zeros(8)
+        v[:len(mod.nodes)] = [vb.get(x, 0.0) for x in mod.nodes]
+        out = np.zeros(64)
+        n = lib().oracle_va_noise(mid, P.ctypes.data_as(pd), v.ctypes.data_as(pd), 303.15, 1e-12, out.ctypes.data_as(pd))
+        assert n == len(it.noise) and n > 0
+        for k, rec in enumerate(it.noise):
+            a, b, pwr, ex = out[4 * k:4 * k + 4]
+            assert mod.nodes[int(a)] == rec["nodes"][0] and (mod.nodes[int(b)] == rec["nodes"][1] if len(rec["nodes"]) > 1 else b == -1)
+            assert pwr == pytest.approx(rec["pwr"], rel=1e-12, abs=1e-300) and ex == pytest.approx(rec["exp"], rel=1e-12)
