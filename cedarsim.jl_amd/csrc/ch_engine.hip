@@ -272,9 +272,17 @@ struct ch_circuit {
       int rep = -1;
       for (int k = 0; k < A.n_comp; ++k) if (A.comp_class[k] == (int)ci) { rep = k; break; }
       int ns = 0;
-      // one lane per device instance; MOSFETs first so that the expensive lanes share wavefronts
-      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind == K_MOS) { blob.push_back(d << 2); ++ns; }
-      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind != K_MOS) { blob.push_back(d << 2); ++ns; }
+      // lane slots, expensive devices first so that they share wavefronts: compiled Verilog-A devices take one lane
+      // per unknown terminal (direction-parallel duals: lane j computes column j of the stamp Jacobians; derivatives
+      // with respect to known nodes are never gathered), MOSFETs and all other devices one lane each
+      for (int d = 0; d < c.ndev; ++d) {
+        const EDev& e = A.edev[A.comp_dofs[rep] + d];
+        if (e.kind != K_VA) continue;
+        bool first = true;
+        for (int j = 0; j < e.nt; ++j) if (e.term[j] >= 0) { blob.push_back((d << 4) | (first ? 8 : 0) | j); first = false; ++ns; }
+      }
+      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind == K_MOS) { blob.push_back(d << 4); ++ns; }
+      for (int d = 0; d < c.ndev; ++d) { const int kd = A.edev[A.comp_dofs[rep] + d].kind; if (kd != K_MOS && kd != K_VA) { blob.push_back(d << 4); ++ns; } }
       m.nslots = ns;
       std::vector<uint16_t> h16(c.mat_src); h16.insert(h16.end(), c.vec_src.begin(), c.vec_src.end());
       if (h16.size() & 1) h16.push_back(0);

@@ -143,11 +143,12 @@ __device__ __forceinline__ void widen_stamp(const double* t, double* st) {
   }
 }
 
-// Evaluate one lane slot of the device-evaluation phase.  slot = (local device << 2) | sub-lane.
+// Evaluate one lane slot of the device-evaluation phase.  slot = (local device << 4) | (first << 3) | direction:
+// compiled Verilog-A devices take one lane per unknown terminal (direction-parallel duals), every other device one lane.
 template <bool WIDE>
 __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int slot, const double* xl, int uofs,
                                           const double* kvl, const double* svl, const double* pl, double* stage) {
-  const int dl = slot >> 2;
+  const int dl = slot >> 4;
   const int d = dofs + dl;
   double* st_final = stage + (size_t)dl * StampLayout<WIDE>::STRIDE;
   const int kind = a.dkind[d];
@@ -158,7 +159,7 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
     for (int k = 0; k < NTERM; ++k) { const int t = tm[k]; vv[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
     const long pi = (long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0);
     const va::Env env{a.temp_k, a.gmin};
-    va_gen::stamp(a.dcls_local[d], a.vapar + a.dsrc[d], vv, env, a.dmult[pi], st_final);
+    va_gen::stamp_dir(a.dcls_local[d], a.vapar + a.dsrc[d], vv, env, a.dmult[pi], slot & 7, (slot & 8) != 0, st_final);
     return;
   }
   double tmp40[WIDE ? 40 : 1];

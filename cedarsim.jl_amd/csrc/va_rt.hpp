@@ -168,4 +168,12 @@ template <int NT, int ND> VA_HD VD<NT, VD<ND, double>> seed(double v, int k, int
   return r;
 }
 
+// one-directional seeds (direction-parallel evaluation)
+VA_HD VD<1, double> seed1(double v, bool is_dir, int /*dk*/, VD<1, double>*) { VD<1, double> r(v); r.d[0] = is_dir ? 1.0 : 0.0; return r; }
+template <int ND> VA_HD VD<1, VD<ND, double>> seed1(double v, bool is_dir, int dk, VD<1, VD<ND, double>>*) {
+  VD<1, VD<ND, double>> r; r.v = VD<ND, double>(v); if (dk >= 0) r.v.d[dk] = 1.0;
+  r.d[0] = VD<ND, double>(is_dir ? 1.0 : 0.0);
+  return r;
+}
+
 }  // namespace va

@@ -620,6 +620,30 @@ def generate_header(modules, source_tag=""):
     out.append("  }")
     out.append("}")
     out.append("")
+    out.append("// Direction-parallel evaluation: one lane per (device, node j) computes the values and the j-th column of the")
+    out.append("// Jacobians with one-directional duals (VD<1,·>); the lane flagged `first` also writes I and Q.")
+    out.append("VA_HD_NOINLINE void stamp_dir(int mod, const double* P, const double* v, const va::Env& env, double m, int dir, bool first, double* st) {")
+    out.append("  switch (mod) {")
+    for i, g in enumerate(gens):
+        mo = g.m
+        nt, nd = len(mo.nodes), len(g.ddx_nodes)
+        R = "va::VD<1, double>" if nd == 0 else "va::VD<1, va::VD<%d, double>>" % nd
+        out.append("    case %d: {" % i)
+        out.append("      typedef %s R;" % R)
+        out.append("      R V[%d], I[%d], Q[%d];" % (nt, nt, nt))
+        for k, node in enumerate(mo.nodes):
+            dk = g.ddx_nodes.index(node) if node in g.ddx_nodes else -1
+            out.append("      V[%d] = va::seed1(v[%d], dir == %d, %d, (R*)nullptr);" % (k, k, k, dk))
+        out.append("      m_%s::eval<R>(P, V, env, I, Q);" % mo.name)
+        out.append("      for (int k = 0; k < %d; ++k) {" % nt)
+        out.append("        if (first) { st[k] = m * va::val(I[k]); st[8 + k] = m * va::val(Q[k]); }")
+        out.append("        st[16 + k * 8 + dir] = m * va::val(I[k].d[0]); st[80 + k * 8 + dir] = m * va::val(Q[k].d[0]);")
+        out.append("      }")
+        out.append("    } break;")
+    out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
+    out.append("")
     out.append("// noise sources of module `mod` at node voltages v: records (node a, node b or -1, power, flicker exponent)")
     out.append("VA_HD_NOINLINE int noise(int mod, const double* P, const double* v, const va::Env& env, va::NoiseRec* out) {")
     out.append("  switch (mod) {")
