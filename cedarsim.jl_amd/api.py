@@ -78,6 +78,30 @@ class Solution:
                     return c.dev_par[i][0] * np.gradient(v, self.t)  # post-processed derivative
         raise KeyError(name)
 
+    def default_name_map(self):
+        """{solution key: column name} for every observed top-level node voltage — default_name_map (src/util.jl:239-260):
+        the `node_` prefix is dropped and ground aliases are left out."""
+        c = self.circuit
+        out = {}
+        for kind, idx in self._cols:
+            if kind != "v":
+                continue
+            name = c.node_names[idx]
+            if "." in name or name in ("0", "gnd"):
+                continue
+            out["node_" + name] = name
+        return out
+
+    def write_csv(self, path, name_map=None):
+        """CSV.write(file, sol; name_map) (ext/CedarSimCSVExt.jl:13-19): column `t` then one column per mapped probe."""
+        name_map = name_map or self.default_name_map()
+        cols = [("t", self.t)] + [(name, self[key]) for key, name in name_map.items()]
+        with open(path, "w") as f:
+            f.write(",".join(n for n, _ in cols) + "\n")
+            for i in range(len(self.t)):
+                f.write(",".join(repr(float(v[i])) for _, v in cols) + "\n")
+        return path
+
     def __call__(self, t, idxs=None):
         """Interpolated observables (linear between saved points; pass `saveat` for exact times)."""
         names = idxs if isinstance(idxs, (list, tuple)) else [idxs]
@@ -284,7 +308,7 @@ class CircuitSweep:
             slots.append(slot)
             values.append(vals)
 
-        from .circuit import (SLOT_DEV_MULT, SLOT_DEV_PAR, SLOT_GMIN, SLOT_MODEL_PAR, SLOT_SRC_DC, SLOT_SRC_PAR, SLOT_TEMP)
+        from .circuit import (SLOT_DEV_MULT, SLOT_DEV_PAR, SLOT_GMIN, SLOT_MODEL_PAR, SLOT_SRC_DC, SLOT_SRC_PAR, SLOT_TEMP, SLOT_VA_PAR)
         par = np.array([c.dev_par for c in circuits], float)          # [P][ndev][8]
         mult = np.array([c.dev_mult for c in circuits], float)
         differs = lambda a: np.any((a != a[0]) & ~(np.isnan(a) & np.isnan(a[0])), axis=0)
@@ -307,6 +331,10 @@ class CircuitSweep:
         if mods.size:
             for m, k in zip(*np.nonzero(differs(mods))):
                 add((SLOT_MODEL_PAR, int(m), int(k)), mods[:, m, k])
+        vap = np.array([c.va_par for c in circuits], float)            # compiled Verilog-A parameter blocks (resolved per point)
+        if vap.size:
+            for i in np.nonzero(differs(vap))[0]:
+                add((SLOT_VA_PAR, int(i), 0), vap[:, i])
         temps = np.array([c.temp for c in circuits])
         if np.any(temps != temps[0]):
             add((SLOT_TEMP, 0, 0), temps)

@@ -19,7 +19,7 @@ DEV_NNODE, DEV_NPAR, DEV_NIPAR = 8, 8, 2
 MOS_W, MOS_L, MOS_NF, MOS_AS, MOS_AD, MOS_PS, MOS_PD = 0, 1, 2, 3, 4, 5, 6
 SRC_DC, SRC_PWL, SRC_PULSE, SRC_SIN = 0, 1, 2, 3
 SRC_NPAR = 8
-SLOT_DEV_PAR, SLOT_MODEL_PAR, SLOT_SRC_DC, SLOT_SRC_PAR, SLOT_TEMP, SLOT_GMIN, SLOT_DEV_MULT = 1, 2, 3, 4, 5, 6, 7
+SLOT_DEV_PAR, SLOT_MODEL_PAR, SLOT_SRC_DC, SLOT_SRC_PAR, SLOT_TEMP, SLOT_GMIN, SLOT_DEV_MULT, SLOT_VA_PAR = 1, 2, 3, 4, 5, 6, 7, 8
 
 OK, ERR_INVALID, ERR_SINGULAR, ERR_MAXITERS, ERR_DTMIN, ERR_DEVICE, ERR_UNSUPPORTED, ERR_MAXSTEPS = 0, -1, -2, -3, -4, -5, -6, -7
 RETCODES = {0: "Success", -1: "Invalid", -2: "Singular", -3: "InitialFailure", -4: "DtLessThanMin",
@@ -311,6 +311,10 @@ class Circuit:
                     s = (SLOT_SRC_DC, si, 0)
                 else:
                     s = (SLOT_SRC_PAR, si, int(fld))
+            elif k == DEV_VA:
+                mod, _ = self.va_instances[nm]
+                names = [p[0].lower() for p in mod.params]
+                s = (SLOT_VA_PAR, self.dev_ipar[i][1] + names.index(mod.aliases.get(fld, fld).lower() if fld not in names else fld), 0)
             elif k == DEV_MOS:
                 s = (SLOT_DEV_PAR, i, {"w": MOS_W, "l": MOS_L, "nf": MOS_NF, "as": MOS_AS, "ad": MOS_AD, "ps": MOS_PS, "pd": MOS_PD}[fld])
             else:

@@ -216,7 +216,7 @@ struct ch_circuit {
   DevBuf<double> d_noise_pwr, d_noise_exp;
   DevBuf<double> d_vapar;
   std::vector<double> va_par;   // parameter blocks of the Verilog-A instances
-  int Stemp = 1;
+  int Stemp = 1, Sva = 1;
   double ac_scale = 0.0;        // eval_sources adds ac_scale*|ac| to every source value (AC right-hand side)  // (d_srcv unused: source values share d_kv)
   DevBuf<unsigned char> d_dmask, d_active;
   DevBuf<BlockOut> d_out;
@@ -389,7 +389,16 @@ struct ch_circuit {
       }
     }
     HIPCHK(d_dpar.upload(hpar, st)); HIPCHK(d_dmult.upload(hmult, st)); HIPCHK(d_gmin.upload(hg, st)); HIPCHK(d_temp.upload(htemp, st));
-    { std::vector<double> vp = va_par; if (vp.empty()) vp.push_back(0.0); HIPCHK(d_vapar.upload(vp, st)); }
+    {  // Verilog-A parameter blocks: one copy, or one per sample when a CH_SLOT_VA_PAR slot is set
+      bool any_va = false;
+      for (int i = 0; i < nslot; ++i) if (slot_set(i) && slot_kind[i] == CH_SLOT_VA_PAR) any_va = true;
+      Sva = any_va ? S : 1;
+      const size_t nvp = std::max<size_t>(1, va_par.size());
+      std::vector<double> vp(nvp * Sva, 0.0);
+      for (int s = 0; s < Sva; ++s) std::copy(va_par.begin(), va_par.end(), vp.begin() + (size_t)s * nvp);
+      for (int i = 0; i < nslot; ++i) if (slot_set(i) && slot_kind[i] == CH_SLOT_VA_PAR) for (int s = 0; s < Sva; ++s) vp[(size_t)s * nvp + slot_a[i]] = slot_val[i][s];
+      HIPCHK(d_vapar.upload(vp, st));
+    }
     // MOS classes: instances with identical (model, geometry, overriding slots) share a column
     const int nmos = (int)A.mos_hdev.size();
     mos_cls.assign(nmos, 0);
@@ -483,7 +492,7 @@ struct ch_circuit {
     a.comp_class = d_comp_class.p; a.comp_uofs = d_comp_uofs.p; a.comp_dofs = d_comp_dofs.p; a.classes = d_classes.p;
     a.blob = d_gl_ptr.p; a.dkind = d_dkind.p; a.dterm = d_dterm.p; a.dsrc = d_dsrc.p; a.dcls = d_dcls.p; a.dhdev = d_dhdev.p;
     a.dpar = d_dpar.p; a.dmult = d_dmult.p; a.mosp = d_mosp.p; a.mos_cols = cols; a.kv = d_kv.p; a.srcv = d_kv.p + (size_t)Ssrc * A.known.size(); a.dmask = d_dmask.p;
-    a.active = nullptr; a.gmin_s = d_gmin.p; a.vapar = d_vapar.p; a.temp_s = d_temp.p; a.Stemp = Stemp;
+    a.active = nullptr; a.gmin_s = d_gmin.p; a.vapar = d_vapar.p; a.va_stride = Sva > 1 ? (long)std::max<size_t>(1, va_par.size()) : 0; a.temp_s = d_temp.p; a.Stemp = Stemp;
     a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = n_dev_src();
     a.n_unk = A.n_unk; a.n_mos_cls = n_cls;
     a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = host_reduce ? h_out : d_out.p;
@@ -1111,6 +1120,7 @@ ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
       case CH_SLOT_SRC_DC: ok = sa >= 0 && sa < (int)c->src.size(); break;
       case CH_SLOT_SRC_PAR: ok = sa >= 0 && sa < (int)c->src.size() && sb >= 0 && sb < CH_SRC_NPAR; break;
       case CH_SLOT_TEMP: case CH_SLOT_GMIN: break;
+      case CH_SLOT_VA_PAR: ok = sa >= 0 && (size_t)sa < c->va_par.size(); break;
       default: ok = false;
     }
     if (!ok) return bad("parameter slot refers to a device, model, source or field that does not exist");
@@ -1168,6 +1178,7 @@ int ch_set_params(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_slots, const 
         case CH_SLOT_SRC_PAR: base = c->src[a].par[b]; break;
         case CH_SLOT_TEMP: base = c->temp; break;
         case CH_SLOT_GMIN: base = c->gmin; break;
+        case CH_SLOT_VA_PAR: base = c->va_par[a]; break;
       }
       v.assign(c->S, base);
     }
@@ -1404,7 +1415,7 @@ int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_i
     }
     NoiseTabArgs t; std::memset(&t, 0, sizeof(t));
     t.dkind = c->d_dkind.p; t.dterm = c->d_dterm.p; t.dsrc = c->d_dsrc.p; t.dcls_local = c->d_dcls_local.p; t.dhdev = c->d_dhdev.p;
-    t.dpar = c->d_dpar.p; t.dmult = c->d_dmult.p; t.vapar = c->d_vapar.p; t.temp_s = c->d_temp.p; t.gmin_s = c->d_gmin.p;
+    t.dpar = c->d_dpar.p; t.dmult = c->d_dmult.p; t.vapar = c->d_vapar.p; t.va_stride = c->base.va_stride; t.temp_s = c->d_temp.p; t.gmin_s = c->d_gmin.p;
     t.X = c->d_X.p; t.kv = c->d_kv.p;  // slot 0 holds the operating point
     t.Spar = c->Spar; t.Stemp = c->Stemp; t.Sgmin = c->Sgmin; t.Ssrc = c->Ssrc; t.nk = (int)A.known.size(); t.S = S; t.n_unk = A.n_unk;
     t.dofs = A.comp_dofs[comp]; t.ndev = ndev_b; t.uofs = uofs; t.nc = ncb;

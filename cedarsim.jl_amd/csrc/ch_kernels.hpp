@@ -67,7 +67,7 @@ struct NewtonArgs {
   const int* dcls_local;                     // per device: index into its block's MOS class list
   const int* comp_mc_ofs; const int* comp_mc_n; const int* mc_list;  // per block: distinct MOS classes
   const double* dpar; const double* dmult;   // [n_hdev * Spar]
-  const double* vapar;                       // parameter blocks of the compiled Verilog-A instances (dsrc[d] = offset, dcls_local[d] = module)
+  const double* vapar; long va_stride;       // parameter blocks of the compiled Verilog-A instances [Sva][va_stride] (dsrc[d] = offset, dcls_local[d] = module; va_stride = 0 when shared by all samples)
   const double* temp_s; int Stemp;           // Celsius per sample ($temperature of Verilog-A modules)
   const double* mosp; long mos_cols;         // packed BSIM4 table [mos_cols][B4I_COUNT]
   const double* kv; const double* srcv;      // known-node values [Ssrc][nk], source values [Ssrc][nsrc]
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
     const int maxit = a.mode == MODE_EVAL ? 1 : a.maxit;
     const double rate_prev = (a.mode == MODE_TRAN && !a.reset_rate) ? a.rate[blk] : 1.0;
     double rate_new = -1.0, dn_prev = 0.0;  // wave 0 only
-    const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar,
+    const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar + (long)s * a.va_stride,
                        WIDE ? a.temp_s[a.Stemp > 1 ? s : 0] + 273.15 : 300.15};
     for (int it = 0; it <= maxit; ++it) {
       // (1) device evaluation → staging (all waves)
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64) void ac_block_kernel(const AcArgs a) {
 // Verilog-A modules.  One thread per (device of the block, sample); every device owns va::MAX_NOISE table entries.
 struct NoiseTabArgs {
   const int* dkind; const int* dterm; const int* dsrc; const int* dcls_local; const int* dhdev;
-  const double* dpar; const double* dmult; const double* vapar; const double* temp_s; const double* gmin_s;
+  const double* dpar; const double* dmult; const double* vapar; long va_stride; const double* temp_s; const double* gmin_s;
   const double* X; const double* kv;   // state (slot already applied) [S][n_unk]; known-node values [Ssrc][nk]
   int Spar, Stemp, Sgmin, Ssrc, nk, S, n_unk, dofs, ndev, uofs, nc;
   int* na; int* nb; double* pwr; double* ex;
@@ -855,7 +855,7 @@ __global__ void noise_table_kernel(const NoiseTabArgs a) {
     for (int k = 0; k < NTERM; ++k) { const int t = tm[k]; vv[k] = t >= 0 ? a.X[(long)s * a.n_unk + t] : a.kv[(long)(a.Ssrc > 1 ? s : 0) * a.nk + (-t - 1)]; }
     va::NoiseRec rec[va::MAX_NOISE];
     const va::Env env{T, a.gmin_s[a.Sgmin > 1 ? s : 0]};
-    const int n = va_gen::noise(a.dcls_local[d], a.vapar + a.dsrc[d], vv, env, rec);
+    const int n = va_gen::noise(a.dcls_local[d], a.vapar + (long)s * a.va_stride + a.dsrc[d], vv, env, rec);
     for (int k = 0; k < n && k < va::MAX_NOISE; ++k) {
       a.na[base + k] = rec[k].a >= 0 ? loc(tm[rec[k].a]) : -1;
       a.nb[base + k] = rec[k].b >= 0 ? loc(tm[rec[k].b]) : -1;

@@ -90,7 +90,8 @@ enum {
   CH_SLOT_SRC_PAR = 4,   /* a = source index, b = par index            */
   CH_SLOT_TEMP = 5,      /* SimSpec.temp  (simulate_ir.jl:15)          */
   CH_SLOT_GMIN = 6,      /* SimSpec.gmin  (simulate_ir.jl:16)          */
-  CH_SLOT_DEV_MULT = 7   /* a = device index: ParallelInstances m      */
+  CH_SLOT_DEV_MULT = 7,  /* a = device index: ParallelInstances m      */
+  CH_SLOT_VA_PAR = 8     /* a = index into ch_desc.va_par (one entry of a compiled Verilog-A instance's parameter block) */
 };
 
 /* Flat circuit description = what a StampExtract overlay over the netlist closure records

@@ -732,6 +732,7 @@ int oracle_set_param(void* h, int slot, double value) {
     case CH_SLOT_SRC_PAR: c->src[a].par[b] = value; break;
     case CH_SLOT_TEMP: c->temp = value; c->sizes_dirty = true; break;
     case CH_SLOT_GMIN: c->gmin = value; break;
+    case CH_SLOT_VA_PAR: if (a < 0 || (size_t)a >= c->va_par.size()) return CH_ERR_INVALID; c->va_par[a] = value; break;
     default: return CH_ERR_INVALID;
   }
   return CH_OK;

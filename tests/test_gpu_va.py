@@ -226,3 +226,36 @@ def test_config5_bsimcmg_asap7_inverter_array(E, O):
     assert rc_o == 0
     assert np.allclose(v[0, :, 0], v_o[0, :, 0], rtol=0, atol=1e-4)
     print("config5: 128 inverters, %d accepted / %d rejected steps, %.3f s wall, %d block iterations" % (st["naccept"], st["nreject"], wall, st["n_block_iters"]))
+
+
+def test_sweep_over_verilog_a_parameters_is_batched(E, O):
+    """CircuitSweep over parameters of compiled modules (ParamSim fields of a VA device, src/circuitodesystem.jl:66-97):
+    all points become samples of one batched solve through CH_SLOT_VA_PAR; each sample must equal its own oracle run."""
+    from cedarsim_jl_amd import CircuitSweep, ProductSweep
+
+    def build(r=1e3, isat=1e-14):
+        c = Circuit(gmin=1e-12)
+        c.V("v1", "in", 0, dc=1.5)
+        c.VA("rs", "va_resistor", ["in", "a"], {"R": r})
+        c.VA("d1", "va_diode", ["a", 0], {"IS": isat, "RS": 2.0})
+        c.observe_node("a")
+        return c
+
+    cs = CircuitSweep(build, ProductSweep(r=[500.0, 1e3, 2e3, 4e3], isat=[1e-15, 1e-13]))
+    sols = dc(cs, abstol=1e-13)
+    assert len(sols) == 8
+    va = []
+    for sol, p in zip(sols, cs):
+        ref = O(build(**p)).dc(dc_opts(abstol=1e-13))[1]
+        assert sol.rc == 0
+        assert sol["node_a"][0] == pytest.approx(ref[build(**p)._n("a") - 1], rel=1e-6)
+        va.append(sol["node_a"][0])
+    assert len(set(np.round(va, 9))) == 8            # every point really got its own parameters
+    # explicit slot on a VA instance parameter
+    c = build()
+    slot = c.slot("rs", "r")
+    eng = E(c)
+    eng.set_samples(3)
+    eng.set_params([slot], [[500.0, 1e3, 4e3]])
+    rc, x, status, st = eng.dc(dc_opts(abstol=1e-13))
+    assert rc == 0 and x[0][c._n("a") - 1] > x[1][c._n("a") - 1] > x[2][c._n("a") - 1]

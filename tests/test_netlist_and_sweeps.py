@@ -114,3 +114,23 @@ def test_shard_range_partitions_exactly():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+def test_solution_name_map_and_csv(tmp_path):
+    """default_name_map (src/util.jl:239-260) and CSV.write(file, sol) (ext/CedarSimCSVExt.jl:13-19) on a Solution
+    object built by hand (no GPU needed: the surface is host-side post-processing)."""
+    import numpy as np
+    from cedarsim_jl_amd import Circuit
+    from cedarsim_jl_amd.api import Solution
+    c = Circuit()
+    c.V("v1", "vcc", 0, dc=1.0)
+    c.R("r1", "vcc", "out", 1e3)
+    c.R("r2", "out", 0, 1e3)
+    t = np.array([0.0, 1.0, 2.0])
+    cols = {("v", c._n("vcc")): np.ones(3), ("v", c._n("out")): np.array([0.5, 0.5, 0.5])}
+    sol = Solution(c, t, cols, None, 0, {})
+    assert sol.default_name_map() == {"node_vcc": "vcc", "node_out": "out"}
+    p = sol.write_csv(str(tmp_path / "sol.csv"))
+    rows = open(p).read().strip().splitlines()
+    assert rows[0] == "t,vcc,out" and rows[1] == "0.0,1.0,0.5" and len(rows) == 4
+    assert sol(1.5, idxs="node_out") == 0.5 and np.allclose(sol["r1.i"], 0.5e-3)
