@@ -206,6 +206,11 @@ class ParsedNetlist:
         for name, (master, params) in parse_spectre_models(text).items():
             self.models.setdefault(name, []).append((name, master, params))
 
+    def add_model_cards(self, cards):
+        """Register model cards given as {name: {"master": module-or-type, "params": {param: value}}}."""
+        for name, card in cards.items():
+            self.models.setdefault(name.lower(), []).append((name.lower(), card["master"].lower(), dict(card["params"])))
+
     # -- SimSpec --
     def _spec(self, overrides):
         temp, gmin, scale = 27.0, 1e-12, 1.0

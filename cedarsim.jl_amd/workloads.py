@@ -199,16 +199,20 @@ VD D 0 AC 1 SIN (0.5 %(amp)g 1e7)
 CMG_TSPAN = (0.0, 4e-7)   # .TRAN 1e-9 4.0e-7 (test/bsimcmg/inverter_cmg_cedar.cir:16)
 
 
-def cmg_inverter_array(n_inverters, card_text, amp=0.01, observe="q0"):
-    """`n_inverters` BSIM-CMG inverters (nmos_lvt / pmos_lvt of the ASAP7 TT card file
-    `card_text`, Spectre language) on shared VDD / VSS / D; every inverter has a private output node.
+def cmg_inverter_array(n_inverters, cards, amp=0.01, observe="q0"):
+    """`n_inverters` BSIM-CMG inverters (nmos_lvt / pmos_lvt of the ASAP7 TT cards: `cards` is
+    either Spectre-language card text or a {name: {"master", "params"}} table such as tests/golden/asap7_tt_lvt_cards.json)
+    on shared VDD / VSS / D; every inverter has a private output node.
     The reference's deck drives D with SIN(0.5 0.01 1e7); `amp` scales that amplitude."""
     insts = []
     for k in range(n_inverters):
         q = "q" if n_inverters == 1 else "q%d" % k
         insts.append("mneg%d %s D VSS VSS nmos_lvt\nmpos%d %s D VDD VDD pmos_lvt" % (k, q, k, q))
     nl = parse_spice(CMG_INVERTER_DECK % {"amp": amp, "insts": "\n".join(insts)})
-    nl.add_spectre_models(card_text)
+    if isinstance(cards, str):
+        nl.add_spectre_models(cards)
+    else:
+        nl.add_model_cards(cards)
     c = nl.build()
     for k in range(n_inverters):
         if observe == "q" or (observe == "q0" and k == 0):

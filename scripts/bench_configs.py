@@ -41,7 +41,7 @@ if only in ("all", "config4"):
                              "block_iterations": st["n_block_iters"], "block_iterations_per_second": st["n_block_iters"] / el,
                              "samples_passing_reference_gate": int(ok.all(axis=0).sum())}
 if only in ("all", "config5"):
-    cards = open(os.path.join(ROOT, "tests", "golden", "asap7_7nm_TT.scs")).read()
+    cards = json.load(open(os.path.join(ROOT, "tests", "golden", "asap7_tt_lvt_cards.json")))["cards"]
     c = cmg_inverter_array(128, cards)
     e = EngineCircuit(c)
     opts = tran_opts(abstol=1e-7, reltol=1e-7, dc=dc_opts(abstol=1e-10, tran_mode=1))

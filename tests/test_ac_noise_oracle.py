@@ -94,7 +94,7 @@ def test_bsimcmg_inverter_noise_matches_reference_ngspice_table():
     f = np.array([r[0] for r in gold["rows"]])
     ng = np.array([r[1] for r in gold["rows"]])
     assert np.allclose(f, acdec(5, 1e3, 1e15), rtol=1e-8)
-    c = cmg_inverter_array(1, open(os.path.join(HERE, "golden", "asap7_7nm_TT.scs")).read())
+    c = cmg_inverter_array(1, json.load(open(os.path.join(HERE, "golden", "asap7_tt_lvt_cards.json")))["cards"])
     rc, psd = Oracle(c).noise(c._n("q") - 1, f, dc_opts(abstol=1e-12))
     assert rc == 0
     assert np.allclose(np.sqrt(psd), ng, rtol=1e-6)

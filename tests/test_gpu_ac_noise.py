@@ -155,7 +155,7 @@ def test_bsimcmg_inverter_noise_matches_ngspice_table_on_the_gpu(E, O):
     gold = json.load(open(os.path.join(HERE, "golden", "ac_bsimcmg_inverter_noise_ngspice.json")))
     f = np.array([r[0] for r in gold["rows"]])
     ng = np.array([r[1] for r in gold["rows"]])
-    c = cmg_inverter_array(1, open(os.path.join(HERE, "golden", "asap7_7nm_TT.scs")).read())
+    c = cmg_inverter_array(1, json.load(open(os.path.join(HERE, "golden", "asap7_tt_lvt_cards.json")))["cards"])
     rc, psd, st = E(c).noise(0, c._n("q"), f, dc_opts(abstol=1e-12))
     assert rc == 0
     assert np.allclose(np.sqrt(psd[0]), ng, rtol=1e-6)

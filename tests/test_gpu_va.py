@@ -2,6 +2,7 @@
 host instantiation and the Python interpreter, circuit-level against the reference's VA tests
 (test/ddx.jl, test/varegress.jl, test/basic.jl:359-381, test/bsimcmg/inverter.jl) and the CPU oracle."""
 import ctypes as C
+import json
 import math
 
 import numpy as np
@@ -200,7 +201,7 @@ def test_bsimcmg_inverter_runs_and_matches_oracle(E, O):
 
 def test_config5_bsimcmg_asap7_inverter_array(E, O):
     """128 BSIM-CMG inverters (256 instances) with the ASAP7 TT cards the reference's parser
-    tests hold (SpectreNetlistParser.jl/test/examples/7nm_TT.scs → tests/golden/asap7_7nm_TT.scs) and the deck of
+    tests hold (SpectreNetlistParser.jl/test/examples/7nm_TT.scs → tests/golden/asap7_tt_lvt_cards.json) and the deck of
     test/bsimcmg/inverter_cmg_cedar.cir (VDD = 1, SIN(0.5 0.01 1e7), 4e-7 s, abstol = reltol = 1e-7 as in
     test/bsimcmg/inverter.jl:20).  The reference asserts `retcode == Success`; here also tile 0 == oracle and
     identical tiles give identical waveforms."""
@@ -209,7 +210,7 @@ def test_config5_bsimcmg_asap7_inverter_array(E, O):
     from cedarsim_jl_amd.workloads import CMG_TSPAN, cmg_inverter_array
     if "bsimcmg" not in load_modules()[1]:
         pytest.skip("bsimcmg was not in the model library build")
-    cards = open(os.path.join(os.path.dirname(__file__), "golden", "asap7_7nm_TT.scs")).read()
+    cards = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "asap7_tt_lvt_cards.json")))["cards"]
     ts = np.linspace(0, 4e-7, 81)
     opts = lambda: tran_opts(abstol=1e-7, reltol=1e-7, saveat=ts, dc=dc_opts(abstol=1e-10, tran_mode=1))  # noqa: E731
     c = cmg_inverter_array(128, cards, observe="q")

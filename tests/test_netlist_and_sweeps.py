@@ -134,3 +134,22 @@ def test_solution_name_map_and_csv(tmp_path):
     rows = open(p).read().strip().splitlines()
     assert rows[0] == "t,vcc,out" and rows[1] == "0.0,1.0,0.5" and len(rows) == 4
     assert sol(1.5, idxs="node_out") == 0.5 and np.allclose(sol["r1.i"], 0.5e-3)
+
+
+def test_spectre_model_card_parser():
+    """`model <name> <master> key=value …` with `+` continuations and `//` comments (the card format of the ASAP7 file the
+    reference's parser tests hold)."""
+    from cedarsim_jl_amd import parse_spectre_models
+    m = parse_spectre_models("""// header
+simulator lang=spectre
+model nmos_x bsimcmg type=n LEVEL = 110
+//+version=110
++  bulkmod = 1   eot = 1e-009  // trailing comment
++  phig=4.3  l = 21n
+model pmos_x bsimcmg type=p
++ phig = 4.8
+resistor1 (a b) resistor r=1k
+""")
+    assert set(m) == {"nmos_x", "pmos_x"}
+    assert m["nmos_x"][0] == "bsimcmg" and m["nmos_x"][1] == {"type": "n", "level": 110.0, "bulkmod": 1.0, "eot": 1e-9, "phig": 4.3, "l": 2.1e-8}
+    assert m["pmos_x"][1] == {"type": "p", "phig": 4.8}
