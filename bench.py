@@ -96,11 +96,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    # CEDARHIP_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the result
+    # gather goes through host memory); the driver's multi-GPU runs use the default: one GPU per rank, RCCL over xGMI
+    backend = os.environ.get("CEDARHIP_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from cedarsim_jl_amd import dc_opts, tran_opts
     from cedarsim_jl_amd.engine import Context, EngineCircuit
@@ -164,7 +172,7 @@ def main():
     tot_iters, max_el = float(iters), el
     all_q = [q]
     if dist is not None:
-        buf = torch.tensor([float(iters), el, float(gate_ok)] + q, dtype=torch.float64, device="cuda")
+        buf = torch.tensor([float(iters), el, float(gate_ok)] + q, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         out = [torch.zeros_like(buf) for _ in range(world)]
         dist.all_gather(out, buf)  # RCCL over xGMI: result gather only
         res = torch.stack(out).cpu().numpy()
