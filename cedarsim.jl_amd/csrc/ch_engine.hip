@@ -505,7 +505,6 @@ struct ch_circuit {
     lds_bytes = (lds_doubles_fixed + A.known.size() + n_dev_src() + (size_t)max_mc * B4I_COUNT) * sizeof(double) + lds_extra_bytes;
     lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
     path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || max_mc > 64 || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
-    if (path == 2 && A.wide) { set_err("compiled Verilog-A devices need Jacobian blocks that fit one CU (no sparse-path support yet)"); return CH_ERR_UNSUPPORTED; }
     if (path == 2) {
       if (S != 1) { set_err("the sparse path (Jacobian blocks larger than one CU's LDS) handles one sample at a time"); return CH_ERR_UNSUPPORTED; }
       int rcs = build_sparse_structure();
@@ -567,8 +566,9 @@ struct ch_circuit {
     for (int d = 0; d < nd; ++d) {
       const EDev& e = A.edev[d];
       bool vm[NTERM], mm[NTERM * NTERM]; kind_mask(e.kind, vm, mm, e.nt);
-      for (int k = 0; k < 4; ++k) if (vm[k] && e.term[k] >= 0) vrows[e.term[k]].push_back(d * 40 + k);
-      for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j) if (mm[k * NTERM + j] && e.term[k] >= 0 && e.term[j] >= 0) rows[e.term[k]][e.term[j]].push_back(d * 40 + 8 + k * 4 + j);
+      const int stride = A.stride(), gofs = A.g_ofs(), gld = A.g_ld();
+      for (int k = 0; k < NTERM; ++k) if (vm[k] && e.term[k] >= 0) vrows[e.term[k]].push_back(d * stride + k);
+      for (int k = 0; k < NTERM; ++k) for (int j = 0; j < NTERM; ++j) if (mm[k * NTERM + j] && e.term[k] >= 0 && e.term[j] >= 0) rows[e.term[k]][e.term[j]].push_back(d * stride + gofs + k * gld + j);
     }
     for (int i = 0; i < n; ++i) rows[i][i];  // structural diagonal (gmin stepping, pivots)
     h_rowptr.assign(1, 0); h_colidx.clear();
@@ -581,7 +581,7 @@ struct ch_circuit {
     const size_t nnz = h_colidx.size();
     HIPCHK(sp_rowptr.upload(h_rowptr, st)); HIPCHK(sp_colidx.upload(h_colidx, st)); HIPCHK(sp_mat_gptr.upload(mgp, st)); HIPCHK(sp_mat_gsrc.upload(mgs, st));
     HIPCHK(sp_vec_gptr.upload(vgp, st)); HIPCHK(sp_vec_gsrc.upload(vgs, st));
-    HIPCHK(sp_stage.alloc((size_t)nd * 40)); HIPCHK(sp_Aval.alloc(nnz)); HIPCHK(sp_Cval.alloc(nnz));
+    HIPCHK(sp_stage.alloc((size_t)nd * A.stride())); HIPCHK(sp_Aval.alloc(nnz)); HIPCHK(sp_Cval.alloc(nnz));
     for (DevBuf<double>* b : {&sp_F, &sp_Q, &sp_rhs, &sp_y, &sp_dx, &sp_xcur, &sp_xpred, &sp_hq, &sp_w, &sp_qn}) HIPCHK(b->alloc(n));
     if (!h_red) { HIPCHK(hipHostMalloc((void**)&h_red, 8 * sizeof(double), hipHostMallocMapped)); HIPCHK(hipHostMalloc((void**)&h_flag, 2 * sizeof(int), hipHostMallocMapped)); }
     { std::vector<int> z(2, 0); HIPCHK(sp_dflag.upload(z, st)); }
@@ -595,6 +595,7 @@ struct ch_circuit {
     d.prow = pd.prow.p; d.pcol = pd.pcol.p; d.a2lu = pd.a2lu.p; d.diag_pos = pd.diag_pos.p; d.lvl_ptr = pd.lvl_ptr.p; d.lvl_rows = pd.lvl_rows.p;
     d.ulvl_ptr = pd.ulvl_ptr.p; d.ulvl_rows = pd.ulvl_rows.p; d.lrow_ptr = pd.lrow_ptr.p; d.l_pos = pd.l_pos.p; d.l_k = pd.l_k.p; d.l_upd_ptr = pd.l_upd_ptr.p;
     d.upd_dst = pd.upd_dst.p; d.upd_src = pd.upd_src.p; d.urow_ptr = pd.urow_ptr.p; d.u_pos = pd.u_pos.p; d.u_col = pd.u_col.p;
+    d.stride = A.stride(); d.q_ofs = A.wide ? 8 : 4; d.c_ofs = A.wide ? 64 : 16; d.wide = A.wide ? 1 : 0;
     d.n = A.n_unk; d.nnz = (int)h_colidx.size(); d.nnz_lu = P.nnz_lu; d.n_lvl = P.valid ? (int)P.lvl_ptr.size() - 1 : 0; d.n_ulvl = P.valid ? (int)P.ulvl_ptr.size() - 1 : 0; d.n_dev = (int)A.edev.size();
     d.stage = sp_stage.p; d.Aval = sp_Aval.p; d.Cval = sp_Cval.p; d.LUv = pd.LUv.p; d.F = sp_F.p; d.Q = sp_Q.p; d.rhs = sp_rhs.p; d.y = sp_y.p; d.dx = sp_dx.p;
     d.xcur = sp_xcur.p; d.xpred = sp_xpred.p; d.hq = sp_hq.p; d.w = sp_w.p; d.qn = sp_qn.p; d.red = h_red; d.flag = h_flag; d.dflag = sp_dflag.p;
@@ -669,7 +670,7 @@ struct ch_circuit {
       bool fresh = false;
       if (!plan[which].valid) { int rc = sparse_plan_from_current(which); if (rc != CH_OK) { status = 2; break; } d = sparse_dev(which); fresh = true; }
       SPDBG("plan ready");
-      const bool damp = a.mode == MODE_DC && a.dv_max > 0.0 && !A.mos_hdev.empty();
+      const bool damp = a.mode == MODE_DC && a.dv_max > 0.0 && (!A.mos_hdev.empty() || A.wide);
       double scale = 1.0;
       bool failed = false;
       for (int attempt = 0; attempt < 2; ++attempt) {

@@ -194,6 +194,7 @@ struct SparseDev {
   const int* lrow_ptr; const int* l_pos; const int* l_k; const int* l_upd_ptr; const int* upd_dst; const int* upd_src;
   const int* urow_ptr; const int* u_pos; const int* u_col;
   int n, nnz, nnz_lu, n_lvl, n_ulvl, n_dev;
+  int stride, q_ofs, c_ofs, wide;  // stamp record layout (40/4/16 narrow, 144/8/64 with compiled Verilog-A devices)
   // work arrays
   double* stage; double* Aval; double* Cval; double* LUv; double* F; double* Q; double* rhs; double* y; double* dx;
   double* xcur; double* xpred; double* hq; double* w; double* qn;
@@ -235,13 +236,28 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
   const int hd = a.dhdev[dev];
   const long pi = (long)hd * a.Spar;
   const double m = a.dmult[pi];
-  double* st = d.stage + (size_t)dev * 40;
+  double* st_final = d.stage + (size_t)dev * d.stride;
   auto srcval = [&](int si) { if (a.inline_vals) { double r = 0.0; for (int q = 0; q < KV_INLINE; ++q) if (q == a.nk + si) r = a.vals_inline[q]; return r; } return a.srcv[si]; };
+  if (kind == K_VA) {
+    double vv[NTERM];
+    for (int k = 0; k < NTERM; ++k) {
+      const int t = tm[k];
+      if (t >= 0) vv[k] = d.xcur[t];
+      else if (a.inline_vals) { double kvv = 0.0; for (int q = 0; q < KV_INLINE; ++q) if (q == -t - 1) kvv = a.vals_inline[q]; vv[k] = kvv; }
+      else vv[k] = kvl[-t - 1];
+    }
+    const va::Env env{a.temp_s[0] + 273.15, a.gmin_s[0]};
+    va_gen::stamp(a.dcls_local[dev], a.vapar + a.dsrc[dev], vv, env, m, st_final);
+    return;
+  }
+  double tmp40[40];
+  double* st = d.wide ? tmp40 : st_final;
   if (kind == K_MOS) {
     const B4Col P = b4_col(a.mosp, (long)a.dcls[dev] * a.Smos);
     double o[40];
     b4_device(P, v[0], v[1], v[2], v[3], a.gmin_s[0], o);
     for (int j = 0; j < 40; ++j) st[j] = m * o[j];
+    if (d.wide) widen_stamp(st, st_final);
     return;
   }
   for (int j = 0; j < 40; ++j) st[j] = 0.0;
@@ -257,6 +273,7 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
     case K_VCVS_B: { const double g = a.dpar[pi]; st[0] = -g * (v[1] - v[2]); st[8 + 1] = -g; st[8 + 2] = g; } break;
     case K_VCCS: { const double g = m * a.dpar[pi], i = g * (v[2] - v[3]); st[0] = i; st[1] = -i; st[8 + 2] = g; st[8 + 3] = -g; st[8 + 6] = -g; st[8 + 7] = g; } break;
   }
+  if (d.wide) widen_stamp(st, st_final);
 }
 
 // CSR gather assembly: one thread per nnz and per row
@@ -265,12 +282,12 @@ __global__ void sp_assemble_kernel(const NewtonArgs a, const SparseDev d) {
   const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
   if (i < d.nnz) {
     double g = 0.0, c = 0.0;
-    for (int p = d.mat_gptr[i]; p < d.mat_gptr[i + 1]; ++p) { const int o = d.mat_gsrc[p]; g += d.stage[o]; c += d.stage[o + 16]; }
+    for (int p = d.mat_gptr[i]; p < d.mat_gptr[i + 1]; ++p) { const int o = d.mat_gsrc[p]; g += d.stage[o]; c += d.stage[o + d.c_ofs]; }
     d.Aval[i] = g + alpha0 * c; d.Cval[i] = c;
   }
   if (i < d.n) {
     double f = 0.0, q = 0.0;
-    for (int p = d.vec_gptr[i]; p < d.vec_gptr[i + 1]; ++p) { const int o = d.vec_gsrc[p]; f += d.stage[o]; q += d.stage[o + 4]; }
+    for (int p = d.vec_gptr[i]; p < d.vec_gptr[i + 1]; ++p) { const int o = d.vec_gsrc[p]; f += d.stage[o]; q += d.stage[o + d.q_ofs]; }
     if (a.gshunt != 0.0 && !(a.dmask[i] & 2)) f += a.gshunt * d.xcur[i];
     d.Q[i] = q;
     const double F = f + alpha0 * q + d.hq[i];

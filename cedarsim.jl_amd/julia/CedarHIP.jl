@@ -22,6 +22,7 @@ struct ChDesc
     n_slot::Int32; slot_kind::Ptr{Int32}; slot_a::Ptr{Int32}; slot_b::Ptr{Int32}
     n_obs::Int32; obs_kind::Ptr{Int32}; obs_index::Ptr{Int32}
     src_ac::Ptr{Float64}   # |ac| per source or C_NULL
+    n_va_par::Int64; va_par::Ptr{Float64}   # parameter blocks of compiled Verilog-A instances or C_NULL
 end
 struct ChDcOpts
     abstol::Float64; maxiters::Int32; n_restarts::Int32; seed::UInt64; tran_mode::Int32; dv_max::Float64; x0::Ptr{Float64}

@@ -341,7 +341,9 @@ static int dc_newton(Circuit& c, std::vector<double>& x, const ch_dc_opts& o, in
     lu_solve(A, n, piv, rhs);
     if (st) { st->nfactors++; st->nsolve++; st->nnonliniter++; }
     double scale = 1.0;
-    if (o.dv_max > 0 && !c.mos_dev.empty()) {  // damping only where nonlinear devices exist; linear circuits take the full Newton step
+    bool has_va = false;
+    for (const Device& d : c.dev) if (d.kind == CH_DEV_VA) { has_va = true; break; }
+    if (o.dv_max > 0 && (!c.mos_dev.empty() || has_va)) {  // damping only where nonlinear devices exist; linear circuits take the full Newton step
       double mx = 0; for (int i = 0; i < c.n_nodes; ++i) mx = std::max(mx, std::fabs(rhs[i]));
       if (mx > o.dv_max) scale = o.dv_max / mx;
     }

@@ -260,3 +260,42 @@ def test_sweep_over_verilog_a_parameters_is_batched(E, O):
     eng.set_params([slot], [[500.0, 1e3, 4e3]])
     rc, x, status, st = eng.dc(dc_opts(abstol=1e-13))
     assert rc == 0 and x[0][c._n("a") - 1] > x[1][c._n("a") - 1] > x[2][c._n("a") - 1]
+
+
+def cmg_chain(n_stages):
+    """Chain of BSIM-CMG inverters (ASAP7 cards): one coupled Jacobian block of 5 unknowns per stage."""
+    import os
+    from cedarsim_jl_amd.netlist import parse_spice as ps
+    cards = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "asap7_tt_lvt_cards.json")))["cards"]
+    lines = ["* chain", "VVDD VDD 0 0.7", "VIN n0 0 PULSE(0 0.7 0.1n 20p 20p 0.4n 1n)"]
+    for k in range(n_stages):
+        lines.append("mn%d n%d n%d 0 0 nmos_lvt" % (k, k + 1, k))
+        lines.append("mp%d n%d n%d VDD VDD pmos_lvt" % (k, k + 1, k))
+        lines.append("cw%d n%d 0 2e-16" % (k, k + 1))
+    nl = ps("\n".join(lines) + "\n.END\n")
+    nl.add_model_cards(cards)
+    c = nl.build()
+    for k in (1, n_stages // 2, n_stages):
+        c.observe_node("n%d" % k)
+    return c
+
+
+@pytest.mark.parametrize("n_stages,path", [(10, 1), (16, 2)])
+def test_coupled_bsimcmg_chain_dense_lds_and_sparse_paths_match_oracle(E, O, n_stages, path):
+    """A coupled block of compiled devices: 10 stages (50 unknowns) runs in the fused kernel with the LDS LU, 16 stages
+    (80 unknowns) takes the sparse path; both against the oracle."""
+    if "bsimcmg" not in load_modules()[1]:
+        pytest.skip("bsimcmg was not in the model library build")
+    c = cmg_chain(n_stages)
+    eng = E(c)
+    ts = np.linspace(0, 1.2e-9, 61)
+    opts = lambda: tran_opts(abstol=1e-7, reltol=1e-6, saveat=ts, dc=dc_opts(abstol=1e-10, tran_mode=1))  # noqa: E731
+    rc, t, v, xf, st = eng.tran(0.0, 1.2e-9, opts())
+    assert rc == 0, eng.ctx.last_error()
+    assert eng.info()["path"] == path and eng.info()["max_component"] == 5 * n_stages
+    rc_o, t_o, v_o, _, _ = O(c).tran(0.0, 1.2e-9, opts())
+    assert rc_o == 0
+    v_o = v_o if v_o.ndim == 3 else v_o[:, :, None]
+    last = v[2, :, 0]
+    assert last.max() > 0.6 and last.min() < 0.1       # the edge propagates to the last stage
+    assert np.allclose(v[:, :, 0], v_o[:, :, 0], rtol=0, atol=1e-4 * 0.7)
