@@ -245,7 +245,8 @@ class Circuit:
         if len(nodes) != len(mod.ports):
             raise CedarError("module %s has %d ports, %d nodes given" % (mod.name, len(mod.ports), len(nodes)))
         it = Interp(mod, params or {}, temperature_c=self.temp, gmin=self.gmin)
-        all_nodes = [self._n(x) for x in nodes] + [self.net("%s.%s" % (name, n)) for n in mod.internal]
+        # internal nets and the branch-current unknowns of voltage branches become circuit nodes of this instance
+        all_nodes = [self._n(x) for x in nodes] + [self.net("%s.%s" % (name, n)) for n in mod.nodes[len(mod.ports):]]
         ofs = len(self.va_par)
         for pname, ty, _, _ in mod.params:
             self.va_par.append(float(it.params[pname]) if ty != "string" else 0.0)
@@ -255,7 +256,7 @@ class Circuit:
         it.evaluate({})
         k = 0
         for acc, nds, kind in it.structure:
-            if acc == "V":
+            if acc == "V" and kind == "collapse":
                 if len(nds) != 2:
                     raise CedarError("V(%s) <+ 0 to ground is not supported" % nds[0])
                 a, b = (all_nodes[mod.nodes.index(x)] for x in nds)

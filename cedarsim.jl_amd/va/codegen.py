@@ -19,7 +19,7 @@ Typing: VA `integer` → int, VA `real` → double unless a fixed-point pass fin
 depend on a node voltage, in which case it is the dual type R.  Analog functions are templates over one
 scalar type S, instantiated with R when any argument is dual.
 """
-from .frontend import FLOW_ACCESS, POTENTIAL_ACCESS, VAError
+from .frontend import FLOW_ACCESS, POTENTIAL_ACCESS, VAError, _is_zero
 
 MAX_NODES = 8
 
@@ -207,10 +207,14 @@ class ModuleGen:
     def probe(self, acc, nodes, ctx):
         if ctx.get("infunc"):
             raise VAError("branch probes inside analog functions are not supported")
-        if acc in FLOW_ACCESS:
-            raise VAError("flow probe %s(%s) is not supported" % (acc, ",".join(nodes)))
         if len(nodes) == 1 and nodes[0] in self.m.branches:
             nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
+        if acc in FLOW_ACCESS:
+            vb = self.m.find_vbranch(nodes)
+            if vb is None:
+                raise VAError("flow probe %s(%s): only the current of a voltage branch can be probed" % (acc, ",".join(nodes)))
+            ty = "real" if ctx.get("noise") else "dual"
+            return ("V[%d]" if vb[1] > 0 else "(-V[%d])") % self.node_ix[vb[0]], ty
         for n in nodes:
             if n not in self.node_ix:
                 raise VAError("unknown node '%s' in module %s" % (n, self.m.name))
@@ -390,9 +394,22 @@ class ModuleGen:
             if len(nodes) == 1 and nodes[0] in self.m.branches:
                 nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
             if acc in POTENTIAL_ACCESS:
-                # V(a,b) <+ 0: node collapse, resolved structurally on the host (the two nodes are merged before
-                # the circuit reaches the engine); any other voltage contribution is rejected there.
-                return ["%s/* V(%s) <+ ...: node collapse handled at circuit build */" % (pad, ",".join(nodes))]
+                if _is_zero(st[3]):
+                    # V(a,b) <+ 0: node collapse, resolved structurally on the host (the two nodes are merged before
+                    # the circuit reaches the engine)
+                    return ["%s/* V(%s) <+ 0: node collapse handled at circuit build */" % (pad, ",".join(nodes))]
+                if ctx.get("noise"):
+                    return []
+                name, sgn = self.m.find_vbranch(nodes)
+                kb = self.node_ix[name]
+                r, q = self.split_ddt(st[3])
+                out = []
+                for ast, arr in ((r, "I"), (q, "Q")):   # branch row: V(a,b) − Σ expr = 0
+                    if ast is None:
+                        continue
+                    c, t = self.expr(ast, ctx)
+                    out.append("%s{ const %s c_ = %s; %s[%d] %s c_; }" % (pad, S, self.cast(c, t, "dual", S), arr, kb, "-=" if sgn > 0 else "+="))
+                return out
             if acc not in FLOW_ACCESS:
                 raise VAError("unknown access function %s" % acc)
             rhs = st[3]
@@ -486,6 +503,11 @@ class ModuleGen:
         """Bit k set: node k receives a ddt() contribution somewhere in the analog block."""
         mask = 0
         for n in _walk(self.m.analog):
+            if n and n[0] == "contrib" and n[1] in POTENTIAL_ACCESS and not _is_zero(n[3]) and _has_ddt(n[3]):
+                nd = list(n[2])
+                if len(nd) == 1 and nd[0] in self.m.branches:
+                    nd = [x for x in self.m.branches[nd[0]] if x is not None]
+                mask |= 1 << self.node_ix[self.m.find_vbranch(nd)[0]]
             if n and n[0] == "contrib" and n[1] in FLOW_ACCESS and _has_ddt(n[3]):
                 nodes = n[2]
                 if len(nodes) == 1 and nodes[0] in self.m.branches:
@@ -545,6 +567,12 @@ class ModuleGen:
             vars_[nm] = t
             out.append("  %s v_%s = 0;" % ({"int": "int", "real": "double", "dual": "R"}[t], nm))
         out.append("  (void)env; (void)V; (void)P;")
+        for key in m.vbranches:   # voltage branches: KCL rows get ±x_br, the branch row starts as V(a) − V(b)
+            kb, a = self.node_ix[m.branch_node(key)], self.node_ix[key[0]]
+            out.append("  I[%d] += V[%d]; I[%d] += V[%d];" % (a, kb, kb, a))
+            if len(key) > 1:
+                b = self.node_ix[key[1]]
+                out.append("  I[%d] -= V[%d]; I[%d] -= V[%d];" % (b, kb, kb, b))
         ctx = {"vars": vars_, "S": "R"}
         for st in m.analog:
             out += self.stmt(st, ctx, 1)

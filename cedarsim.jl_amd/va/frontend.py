@@ -56,6 +56,10 @@ class VAError(Exception):
     pass
 
 
+def _is_zero(e):
+    return e[0] == "num" and e[1] == 0
+
+
 # ------------------------------------------------------------------------------------------------
 # preprocessor
 def _strip_comments(text):
@@ -299,8 +303,47 @@ class Module:
         self.analog = []      # analog statements in order
 
     @property
+    def vbranches(self):
+        """Voltage branches: (a, b) pairs that receive a `V(a,b) <+ expr` contribution other than the literal 0 (which is a
+        node collapse).  Each gets a branch-current unknown, carried as a pseudo-node after the internal nets."""
+        if getattr(self, "_vb", None) is None:
+            out = []
+
+            def walk(st):
+                if isinstance(st, tuple):
+                    if st and st[0] == "contrib" and st[1] in POTENTIAL_ACCESS and not _is_zero(st[3]):
+                        nodes = list(st[2])
+                        if len(nodes) == 1 and nodes[0] in self.branches:
+                            nodes = [x for x in self.branches[nodes[0]] if x is not None]
+                        key = tuple(nodes)
+                        if key not in out and tuple(reversed(key)) not in out:
+                            out.append(key)
+                    for c in st:
+                        walk(c)
+                elif isinstance(st, list):
+                    for c in st:
+                        walk(c)
+            walk(self.analog)
+            self._vb = out
+        return self._vb
+
+    @staticmethod
+    def branch_node(key):
+        return "I(" + ",".join(key) + ")"
+
+    @property
     def nodes(self):
-        return self.ports + self.internal
+        return self.ports + self.internal + [self.branch_node(k) for k in self.vbranches]
+
+    def find_vbranch(self, nodes):
+        """(pseudo-node name, sign) of the voltage branch between `nodes`, or None."""
+        key = tuple(nodes)
+        for k in self.vbranches:
+            if k == key:
+                return self.branch_node(k), 1.0
+            if tuple(reversed(k)) == key and len(k) == 2:
+                return self.branch_node(k), -1.0
+        return None
 
 
 _BINPREC = [("||",), ("&&",), ("|",), ("^",), ("&",), ("==", "!="), ("<", "<=", ">", ">="), ("<<", ">>"), ("+", "-"), ("*", "/", "%"), ("**",)]

@@ -13,7 +13,7 @@ output/inout arguments (vasim.jl:426-454), `case` (vasim.jl:603-626).
 """
 import math
 
-from .frontend import FLOW_ACCESS, POTENTIAL_ACCESS, VAError
+from .frontend import FLOW_ACCESS, POTENTIAL_ACCESS, VAError, _is_zero
 
 KB, QE = 1.3806503e-23, 1.602176462e-19   # P_K, P_Q of constants.vams ($vt)
 
@@ -374,6 +374,17 @@ class Interp:
         fr = _Frame(m.vars)
         for nm, ty in m.vars.items():
             fr.vals[nm] = 0 if ty == "integer" else 0.0
+        # voltage branches: unknown branch current x_br; KCL rows get ±x_br, the branch row starts as V(a) − V(b)
+        for key in m.vbranches:
+            kb = self.node_ix[m.branch_node(key)]
+            xb = self.V[m.branch_node(key)]
+            a = self.node_ix[key[0]]
+            self.Ires[a] = self.Ires[a] + xb
+            self.Ires[kb] = self.Ires[kb] + self.V[key[0]]
+            if len(key) > 1:
+                b = self.node_ix[key[1]]
+                self.Ires[b] = self.Ires[b] - xb
+                self.Ires[kb] = self.Ires[kb] - self.V[key[1]]
         for st in m.analog:
             self.ex(st, fr)
         self.structure = list(self.contribs)
@@ -419,7 +430,12 @@ class Interp:
                 nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
             a = self.V[nodes[0]]
             return a - self.V[nodes[1]] if len(nodes) > 1 else a
-        raise VAError("flow probe %s(%s) is not supported" % (acc, ",".join(nodes)))
+        if len(nodes) == 1 and nodes[0] in self.m.branches:
+            nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
+        vb = self.m.find_vbranch(nodes)
+        if vb is not None:   # current of a voltage branch = its branch unknown
+            return self.V[vb[0]] * vb[1]
+        raise VAError("flow probe %s(%s): only the current of a voltage branch can be probed" % (acc, ",".join(nodes)))
 
     def ev(self, e, fr):
         k = e[0]
@@ -592,10 +608,16 @@ class Interp:
             if len(nodes) == 1 and nodes[0] in self.m.branches:
                 nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
             if acc in POTENTIAL_ACCESS:
-                v = self.ev(st[3], fr)
-                if val(v) != 0.0 or isinstance(v, D) and any(val(x) != 0 for x in v.d):
-                    raise VAError("voltage contributions other than V(a,b) <+ 0 (node collapse) are not supported")
-                self.contribs.append(("V", tuple(nodes), "collapse"))
+                if _is_zero(st[3]):
+                    self.contribs.append(("V", tuple(nodes), "collapse"))
+                    return
+                name, sgn = self.m.find_vbranch(nodes)
+                kb = self.node_ix[name]
+                r, q = self.split_ddt(st[3], fr)
+                self.Ires[kb] = self.Ires[kb] - sgn * r          # branch row: V(a,b) − Σ expr = 0
+                if q is not None:
+                    self.Qres[kb] = self.Qres[kb] - sgn * q
+                self.contribs.append(("V", tuple(nodes), "branch"))
                 return
             if st[3][0] == "call" and st[3][1] in ("white_noise", "flicker_noise"):
                 args = st[3][2]

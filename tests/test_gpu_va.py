@@ -299,3 +299,22 @@ def test_coupled_bsimcmg_chain_dense_lds_and_sparse_paths_match_oracle(E, O, n_s
     last = v[2, :, 0]
     assert last.max() > 0.6 and last.min() < 0.1       # the edge propagates to the last stage
     assert np.allclose(v[:, :, 0], v_o[:, :, 0], rtol=0, atol=1e-4 * 0.7)
+
+
+def test_voltage_contributions_on_the_gpu(E, O):
+    c = Circuit()
+    c.V("v1", "in", 0, dc=1.0)
+    c.R("r1", "in", "a", 100.0)
+    c.VA("l1", "va_inductor", ["a", 0], {"L": 1e-3, "RS": 0.0})
+    c.observe_node("a")
+    c.observe_node("l1.i(p,n)")
+    rc, t, v, xf, st = E(c).tran(0.0, 5e-5, tran_opts(abstol=1e-10, reltol=1e-7, skip_dc=1))
+    assert rc == 0
+    assert np.allclose(v[1, :, 0], 1.0 / 100.0 * (1 - np.exp(-t / 1e-5)), rtol=1e-4, atol=1e-8)
+    c = Circuit()
+    c.V("vc", "c", 0, dc=0.25)
+    c.VA("e1", "va_vcvs", ["out", 0, "c", 0], {"VDC": 1.5, "GAIN": -2.0})
+    c.R("rl", "out", 0, 50.0)
+    rc, x, status, st = E(c).dc(dc_opts(abstol=1e-14))
+    assert rc == 0 and x[0][c._n("out") - 1] == pytest.approx(1.0, rel=1e-12)
+    assert x[0][c._n("e1.i(p,n)") - 1] == pytest.approx(-1.0 / 50.0, rel=1e-12)

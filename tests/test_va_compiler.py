@@ -126,7 +126,8 @@ def test_generated_code_matches_interpreter_library_models():
     rng = np.random.default_rng(5)
     for name, params in (("va_resistor", {"R": 2e3}), ("va_resistor_rev", {}), ("va_nlvcr", {"R": 2.0}), ("va_capacitor", {"C": 3e-12}),
                          ("va_diode", {"IS": 2e-14, "RS": 5.0, "LEVEL": 2}), ("va_diode", {}), ("va_mos1", {"TYPE": -1, "W": 4e-6, "CGSO": 1e-10}),
-                         ("va_mos1", {"KP": 2e-4})):
+                         ("va_mos1", {"KP": 2e-4}), ("va_inductor", {"L": 2e-6, "RS": 3.0}), ("va_vcvs", {"VDC": 1.5, "GAIN": -2.0}),
+                         ("va_noisy_resistor", {"KF": 1e-12})):
         _, mod = find_module(name)
         _codegen_vs_interp(name, params, [_random_bias(mod, rng) for _ in range(6)], temp_c=40.0)
 
@@ -209,3 +210,29 @@ def test_generated_noise_records_match_interpreter():
             a, b, pwr, ex = out[4 * k:4 * k + 4]
             assert mod.nodes[int(a)] == rec["nodes"][0] and (mod.nodes[int(b)] == rec["nodes"][1] if len(rec["nodes"]) > 1 else b == -1)
             assert pwr == pytest.approx(rec["pwr"], rel=1e-12, abs=1e-300) and ex == pytest.approx(rec["exp"], rel=1e-12)
+
+
+def test_voltage_contributions_and_branch_current_probe():
+    """`V(a,b) <+ expr` with `I(a,b)` probes (voltage form of a branch equation, src/vasim.jl:128-180, 810-822): the branch
+    current is an extra unknown of the instance.  RL step response and a VA-defined source against closed forms."""
+    _, ind = find_module("va_inductor")
+    assert ind.nodes == ["p", "n", "I(p,n)"] and ind.vbranches == [("p", "n")]
+    c = Circuit()
+    c.V("v1", "in", 0, dc=1.0)
+    c.R("r1", "in", "a", 100.0)
+    c.VA("l1", "va_inductor", ["a", 0], {"L": 1e-3, "RS": 0.0})
+    c.observe_node("a")
+    c.observe_node("l1.i(p,n)")
+    rc, t, v, xf, st = Oracle(c).tran(0.0, 5e-5, tran_opts(abstol=1e-10, reltol=1e-7, skip_dc=1))
+    assert rc == 0
+    v = v if v.ndim == 2 else v[:, :, 0]
+    tau = 1e-3 / 100.0
+    assert np.allclose(v[1], 1.0 / 100.0 * (1 - np.exp(-t / tau)), rtol=1e-4, atol=1e-8)
+    # DC: the inductor is a short, a VA source sets a node: out = VDC + GAIN*V(c) = 1.5 - 2*0.25
+    c = Circuit()
+    c.V("vc", "c", 0, dc=0.25)
+    c.VA("e1", "va_vcvs", ["out", 0, "c", 0], {"VDC": 1.5, "GAIN": -2.0})
+    c.R("rl", "out", 0, 50.0)
+    rc, x, _ = Oracle(c).dc(dc_opts(abstol=1e-14))
+    assert rc == 0 and x[c._n("out") - 1] == pytest.approx(1.0, rel=1e-12)
+    assert x[c._n("e1.i(p,n)") - 1] == pytest.approx(-1.0 / 50.0, rel=1e-12)   # current through the branch p -> n
