@@ -236,3 +236,16 @@ def test_voltage_contributions_and_branch_current_probe():
     rc, x, _ = Oracle(c).dc(dc_opts(abstol=1e-14))
     assert rc == 0 and x[c._n("out") - 1] == pytest.approx(1.0, rel=1e-12)
     assert x[c._n("e1.i(p,n)") - 1] == pytest.approx(-1.0 / 50.0, rel=1e-12)   # current through the branch p -> n
+
+
+def test_front_end_rejects_the_reference_parsers_error_cases():
+    """VerilogAParser.jl/test/errors/*.va: malformed sources the reference's parser must diagnose.  The front-end has to
+    raise VAError on every one (never crash or hang).  Runs where the reference checkout is present."""
+    import glob
+    from cedarsim_jl_amd.va.frontend import parse_va_file
+    files = sorted(glob.glob("/root/reference/VerilogAParser.jl/test/errors/*.va"))
+    if not files:
+        pytest.skip("reference checkout not present")
+    for f in files:
+        with pytest.raises(VAError):
+            parse_va_file(f)
