@@ -302,9 +302,6 @@ class ModuleGen:
         ev = [self.expr(a, ctx) if kind != "output" else (None, None) for (nm, kind), a in zip(f.args, args)]
         # outputs whose target variable is dual force the dual instantiation as well
         anydual = any(t == "dual" for c, t in ev if c is not None)
-        for (nm, kind), a in zip(f.args, args):
-            if kind in ("output", "inout") and a[0] == "id" and ctx["vars"].get(a[1]) == "dual":
-                anydual = anydual or False
         FS = S if anydual else "double"
         fty = "dual" if anydual else "real"
         call_args, pre, post = [], [], []
@@ -552,20 +549,23 @@ class ModuleGen:
                 used.add(n[1])
             if n and n[0] == "call" and n[1] in ("$param_given", "$given"):
                 used.add("?" + m.aliases.get(n[2][0][1], n[2][0][1]))
+        param_decls = []
         for i, (nm, ty, _, _) in enumerate(m.params):
             if ty == "string":
                 continue
             if nm in used:
-                out.append("  const %s p_%s = %sP[%d];" % ("int" if ty == "integer" else "double", nm, "(int)" if ty == "integer" else "", i))
+                param_decls.append("  const %s p_%s = %sP[%d];" % ("int" if ty == "integer" else "double", nm, "(int)" if ty == "integer" else "", i))
             if "?" + nm in used:
-                out.append("  const int g_%s = P[%d] != 0.0 ? 1 : 0;" % (nm, np_ + i))
+                param_decls.append("  const int g_%s = P[%d] != 0.0 ? 1 : 0;" % (nm, np_ + i))
         vars_ = {}
         for nm, ty in m.vars.items():
             if ty == "string":
                 continue
-            t = "int" if ty == "integer" else ("dual" if nm in self.dual else "real")
-            vars_[nm] = t
-            out.append("  %s v_%s = 0;" % ({"int": "int", "real": "double", "dual": "R"}[t], nm))
+            vars_[nm] = "int" if ty == "integer" else ("dual" if nm in self.dual else "real")
+
+        def var_decls(scalar):
+            return ["  %s v_%s = 0;" % ({"int": "int", "real": "double", "dual": scalar}[t], nm) for nm, t in vars_.items()]
+        out += param_decls + var_decls("R")
         out.append("  (void)env; (void)V; (void)P;")
         for key in m.vbranches:   # voltage branches: KCL rows get ±x_br, the branch row starts as V(a) − V(b)
             kb, a = self.node_ix[m.branch_node(key)], self.node_ix[key[0]]
@@ -580,11 +580,9 @@ class ModuleGen:
         # noise pass: same statements over plain doubles, contributions replaced by noise records
         self.has_noise = any(n and n[0] == "call" and n[1] in ("white_noise", "flicker_noise") for n in _walk(m.analog))
         if self.has_noise:
-            body_start = next(i for i, l in enumerate(out) if l.startswith("template <class R> VA_HD_NOINLINE void eval("))
-            decls = [l for l in out[body_start + 1:] if l.startswith("  const ") or (l.startswith("  ") and " v_" in l and l.rstrip().endswith("= 0;") and not l.startswith("   "))]
             out.append("VA_HD_NOINLINE int noise(const double* P, const double* V, const va::Env& env, va::NoiseRec* out) {")
-            out.append("  typedef double R; int n_ = 0;")
-            out += [l.replace(" R v_", " double v_") for l in decls]
+            out.append("  int n_ = 0;")
+            out += param_decls + var_decls("double")
             out.append("  (void)env; (void)V; (void)P;")
             nctx = {"vars": {k: ("real" if t == "dual" else t) for k, t in vars_.items()}, "S": "double", "noise": True}
             self.dual_saved, self.dual = self.dual, set()
