@@ -235,7 +235,9 @@ struct ch_circuit {
   DevBuf<int> sp_rowptr, sp_colidx, sp_mat_gptr, sp_mat_gsrc, sp_vec_gptr, sp_vec_gsrc;
   DevBuf<double> sp_stage, sp_Aval, sp_Cval, sp_F, sp_Q, sp_rhs, sp_y, sp_dx, sp_xcur, sp_xpred, sp_hq, sp_w, sp_qn;
   std::vector<int> h_rowptr, h_colidx;
-  double* h_red = nullptr; int* h_flag = nullptr;  // mapped pinned
+  double* h_red = nullptr; int* h_flag = nullptr;  // mapped pinned: [S][8], [S][2]
+  size_t h_red_n = 0;
+  std::vector<double> sp_rate_v; std::vector<int> sp_status_v;  // per sample: last Newton rate, status of the last solve
   double sp_rate = 1.0;
   // stats
   double device_ms = 0; long n_launch = 0, n_timed = 0;  // device_ms sums the sampled launches only
@@ -506,7 +508,6 @@ struct ch_circuit {
     lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
     path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || max_mc > 64 || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
     if (path == 2) {
-      if (S != 1) { set_err("the sparse path (Jacobian blocks larger than one CU's LDS) handles one sample at a time"); return CH_ERR_UNSUPPORTED; }
       int rcs = build_sparse_structure();
       if (rcs != CH_OK) return rcs;
       lds_bytes = 0;
@@ -581,33 +582,46 @@ struct ch_circuit {
     const size_t nnz = h_colidx.size();
     HIPCHK(sp_rowptr.upload(h_rowptr, st)); HIPCHK(sp_colidx.upload(h_colidx, st)); HIPCHK(sp_mat_gptr.upload(mgp, st)); HIPCHK(sp_mat_gsrc.upload(mgs, st));
     HIPCHK(sp_vec_gptr.upload(vgp, st)); HIPCHK(sp_vec_gsrc.upload(vgs, st));
-    HIPCHK(sp_stage.alloc((size_t)nd * A.stride())); HIPCHK(sp_Aval.alloc(nnz)); HIPCHK(sp_Cval.alloc(nnz));
-    for (DevBuf<double>* b : {&sp_F, &sp_Q, &sp_rhs, &sp_y, &sp_dx, &sp_xcur, &sp_xpred, &sp_hq, &sp_w, &sp_qn}) HIPCHK(b->alloc(n));
-    if (!h_red) { HIPCHK(hipHostMalloc((void**)&h_red, 8 * sizeof(double), hipHostMallocMapped)); HIPCHK(hipHostMalloc((void**)&h_flag, 2 * sizeof(int), hipHostMallocMapped)); }
-    { std::vector<int> z(2, 0); HIPCHK(sp_dflag.upload(z, st)); }
+    HIPCHK(sp_stage.alloc((size_t)S * nd * A.stride())); HIPCHK(sp_Aval.alloc((size_t)S * nnz)); HIPCHK(sp_Cval.alloc((size_t)S * nnz));
+    for (DevBuf<double>* b : {&sp_F, &sp_Q, &sp_rhs, &sp_y, &sp_dx, &sp_xcur, &sp_xpred, &sp_hq, &sp_w, &sp_qn}) HIPCHK(b->alloc((size_t)S * n));
+    if (h_red_n < (size_t)S) {
+      if (h_red) (void)hipHostFree(h_red);
+      if (h_flag) (void)hipHostFree(h_flag);
+      h_red = nullptr; h_flag = nullptr;
+      HIPCHK(hipHostMalloc((void**)&h_red, (size_t)S * 8 * sizeof(double), hipHostMallocMapped)); HIPCHK(hipHostMalloc((void**)&h_flag, (size_t)S * 2 * sizeof(int), hipHostMallocMapped));
+      h_red_n = (size_t)S;
+    }
+    { std::vector<int> z((size_t)S, 0); HIPCHK(sp_dflag.upload(z, st)); }
+    sp_rate_v.assign(S, 1.0); sp_status_v.assign(S, 0);
     plan[0].valid = plan[1].valid = false;
     return CH_OK;
   }
-  SparseDev sparse_dev(int which) {
+  SparseDev sparse_dev(int which, int sm = 0) {
     SparseDev d; std::memset(&d, 0, sizeof(d));
     PlanDev& pd = plan_dev[which]; const SparsePlan& P = plan[which];
+    const size_t n = A.n_unk, nnz = h_colidx.size(), nd = A.edev.size();
     d.rowptr = sp_rowptr.p; d.colidx = sp_colidx.p; d.mat_gptr = sp_mat_gptr.p; d.mat_gsrc = sp_mat_gsrc.p; d.vec_gptr = sp_vec_gptr.p; d.vec_gsrc = sp_vec_gsrc.p;
     d.prow = pd.prow.p; d.pcol = pd.pcol.p; d.a2lu = pd.a2lu.p; d.diag_pos = pd.diag_pos.p; d.lvl_ptr = pd.lvl_ptr.p; d.lvl_rows = pd.lvl_rows.p;
     d.ulvl_ptr = pd.ulvl_ptr.p; d.ulvl_rows = pd.ulvl_rows.p; d.lrow_ptr = pd.lrow_ptr.p; d.l_pos = pd.l_pos.p; d.l_k = pd.l_k.p; d.l_upd_ptr = pd.l_upd_ptr.p;
     d.upd_dst = pd.upd_dst.p; d.upd_src = pd.upd_src.p; d.urow_ptr = pd.urow_ptr.p; d.u_pos = pd.u_pos.p; d.u_col = pd.u_col.p;
+    d.s = sm; d.xofs = (long)sm * (long)n;
     d.stride = A.stride(); d.q_ofs = A.wide ? 8 : 4; d.c_ofs = A.wide ? 64 : 16; d.wide = A.wide ? 1 : 0;
-    d.n = A.n_unk; d.nnz = (int)h_colidx.size(); d.nnz_lu = P.nnz_lu; d.n_lvl = P.valid ? (int)P.lvl_ptr.size() - 1 : 0; d.n_ulvl = P.valid ? (int)P.ulvl_ptr.size() - 1 : 0; d.n_dev = (int)A.edev.size();
-    d.stage = sp_stage.p; d.Aval = sp_Aval.p; d.Cval = sp_Cval.p; d.LUv = pd.LUv.p; d.F = sp_F.p; d.Q = sp_Q.p; d.rhs = sp_rhs.p; d.y = sp_y.p; d.dx = sp_dx.p;
-    d.xcur = sp_xcur.p; d.xpred = sp_xpred.p; d.hq = sp_hq.p; d.w = sp_w.p; d.qn = sp_qn.p; d.red = h_red; d.flag = h_flag; d.dflag = sp_dflag.p;
+    d.n = A.n_unk; d.nnz = (int)nnz; d.nnz_lu = P.nnz_lu; d.n_lvl = P.valid ? (int)P.lvl_ptr.size() - 1 : 0; d.n_ulvl = P.valid ? (int)P.ulvl_ptr.size() - 1 : 0; d.n_dev = (int)nd;
+    // per-sample slices of the work arrays
+    d.stage = sp_stage.p + (size_t)sm * nd * A.stride(); d.Aval = sp_Aval.p + (size_t)sm * nnz; d.Cval = sp_Cval.p + (size_t)sm * nnz;
+    d.LUv = pd.LUv.p ? pd.LUv.p + (size_t)sm * (size_t)std::max(0, P.nnz_lu) : nullptr;
+    d.F = sp_F.p + sm * n; d.Q = sp_Q.p + sm * n; d.rhs = sp_rhs.p + sm * n; d.y = sp_y.p + sm * n; d.dx = sp_dx.p + sm * n;
+    d.xcur = sp_xcur.p + sm * n; d.xpred = sp_xpred.p + sm * n; d.hq = sp_hq.p + sm * n; d.w = sp_w.p + sm * n; d.qn = sp_qn.p + sm * n;
+    d.red = h_red + (size_t)sm * 8; d.flag = h_flag + (size_t)sm * 2; d.dflag = sp_dflag.p + sm;
     return d;
   }
   // host analysis from the current numeric values of A (KLU-style: analyse once, refactor many times)
-  int sparse_plan_from_current(int which) {
+  int sparse_plan_from_current(int which, int sm = 0) {
     g_arena = &arena;
     hipStream_t st = ctx->stream;
     std::vector<double> aval(h_colidx.size());
     HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipMemcpy(aval.data(), sp_Aval.p, aval.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(aval.data(), sp_Aval.p + (size_t)sm * aval.size(), aval.size() * sizeof(double), hipMemcpyDeviceToHost));
     SparsePlan& P = plan[which];
     int rc = sparse_analyse(A.n_unk, h_rowptr, h_colidx, aval, P);
     if (rc != CH_OK) { set_err("sparse analysis: structurally singular Jacobian"); return rc; }
@@ -616,7 +630,7 @@ struct ch_circuit {
     HIPCHK(pd.lvl_ptr.upload(P.lvl_ptr, st)); HIPCHK(pd.lvl_rows.upload(P.lvl_rows, st)); HIPCHK(pd.ulvl_ptr.upload(P.ulvl_ptr, st)); HIPCHK(pd.ulvl_rows.upload(P.ulvl_rows, st));
     HIPCHK(pd.lrow_ptr.upload(P.lrow_ptr, st)); HIPCHK(pd.l_pos.upload(P.l_pos, st)); HIPCHK(pd.l_k.upload(P.l_k, st)); HIPCHK(pd.l_upd_ptr.upload(P.l_upd_ptr, st));
     HIPCHK(pd.upd_dst.upload(P.upd_dst, st)); HIPCHK(pd.upd_src.upload(P.upd_src, st)); HIPCHK(pd.urow_ptr.upload(P.urow_ptr, st)); HIPCHK(pd.u_pos.upload(P.u_pos, st)); HIPCHK(pd.u_col.upload(P.u_col, st));
-    HIPCHK(pd.LUv.alloc((size_t)P.nnz_lu));
+    HIPCHK(pd.LUv.alloc((size_t)S * (size_t)P.nnz_lu));
     return CH_OK;
   }
   int sp_sync() {
@@ -627,11 +641,10 @@ struct ch_circuit {
     if (q != hipSuccess) { set_err(std::string("sparse path: ") + hipGetErrorString(q)); return CH_ERR_DEVICE; }
     return CH_OK;
   }
-  // One Newton solve (same contract as the fused kernel: reads the history ring, writes the candidate slot)
-  int run_sparse(NewtonArgs a, Summary& out) {
-    const bool dbg = std::getenv("CEDARHIP_DEBUG") != nullptr;
-#define SPDBG(msg) do { if (dbg) { std::fprintf(stderr, "[sp] %s\n", msg); std::fflush(stderr); } } while (0)
-    SPDBG("enter");
+  // One Newton solve per sample (same contract as the fused kernel: reads the history ring, writes the candidate
+  // slot).  Samples share the symbolic plan and the pivot order; every phase is queued for all active samples and
+  // the host synchronises once per phase, so the number of round trips does not grow with the sample count.
+  int run_sparse(NewtonArgs a, const unsigned char* host_active, Summary& out) {
     hipStream_t st = ctx->stream;
     const int which = a.mode == MODE_DC ? 0 : 1;
     const int n = A.n_unk, nd = (int)A.edev.size(), nnz = (int)h_colidx.size();
@@ -641,81 +654,109 @@ struct ch_circuit {
       HIPCHK(hipMemcpyAsync(d_kv.p, h_stage, (size_t)(a.nk + a.nsrc) * sizeof(double), hipMemcpyHostToDevice, st));
       a.inline_vals = 0;
     }
-    SparseDev d = sparse_dev(which);
     const dim3 b256(256), gn((n + 255) / 256), gd((nd + 63) / 64), ga((std::max(n, nnz) + 255) / 256);
     std::memset(&out, 0, sizeof(out));
-    hipLaunchKernelGGL(sp_predict_kernel, gn, b256, 0, st, a, d);
-    SPDBG("predict launched");
     const int maxit = a.mode == MODE_EVAL ? 0 : a.maxit;
-    const double rate_prev = (a.mode == MODE_TRAN && !a.reset_rate) ? sp_rate : 1.0;
-    double rate_new = -1.0, dn_prev = 0.0;
-    int status = 1, iters = 0;
-    double fnorm = 0.0;
-    for (int it = 0; it <= maxit; ++it) {
-      hipLaunchKernelGGL(sp_eval_kernel, gd, dim3(64), 0, st, a, d);
-      hipLaunchKernelGGL(sp_assemble_kernel, ga, b256, 0, st, a, d);
-      if (a.gshunt != 0.0) hipLaunchKernelGGL(sp_diag_shunt_kernel, gn, b256, 0, st, a, d);
-      n_launch += 2;
-      SPDBG("assembled");
-      if (a.mode == MODE_EVAL) { status = 0; break; }
+    std::vector<int> todo;   // samples taking part in this solve
+    for (int sm = 0; sm < S; ++sm) {   // a sample takes part when any of its blocks is active (the sparse system spans all blocks)
+      bool on = !host_active;
+      for (int k = 0; k < A.n_comp && !on; ++k) on = host_active[(size_t)k * S + sm] != 0;
+      if (on) todo.push_back(sm);
+    }
+    std::vector<int> status(S, 1), iters(S, 0);
+    std::vector<double> rate_prev(S, 1.0), rate_new(S, -1.0), dn_prev(S, 0.0), fnorm(S, 0.0), scale(S, 1.0);
+    for (int sm : todo) { rate_prev[sm] = (a.mode == MODE_TRAN && !a.reset_rate) ? sp_rate_v[sm] : 1.0; hipLaunchKernelGGL(sp_predict_kernel, gn, b256, 0, st, a, sparse_dev(which, sm)); }
+    std::vector<int> act = todo;   // samples still iterating
+    const bool damp = a.mode == MODE_DC && a.dv_max > 0.0 && (!A.mos_hdev.empty() || A.wide);
+    for (int it = 0; it <= maxit && !act.empty(); ++it) {
+      for (int sm : act) {
+        const SparseDev d = sparse_dev(which, sm);
+        hipLaunchKernelGGL(sp_eval_kernel, gd, dim3(64), 0, st, a, d);
+        hipLaunchKernelGGL(sp_assemble_kernel, ga, b256, 0, st, a, d);
+        if (a.gshunt != 0.0) hipLaunchKernelGGL(sp_diag_shunt_kernel, gn, b256, 0, st, a, d);
+        if (a.mode == MODE_DC) hipLaunchKernelGGL(sp_norms_kernel, dim3(1), dim3(1024), 0, st, a, d, 0);
+        n_launch += 2;
+      }
+      if (a.mode == MODE_EVAL) { for (int sm : act) status[sm] = 0; break; }
       if (a.mode == MODE_DC) {
-        hipLaunchKernelGGL(sp_norms_kernel, dim3(1), dim3(1024), 0, st, a, d, 0);
         int rc = sp_sync(); if (rc != CH_OK) return rc;
-        fnorm = h_red[0];
-        if (!(fnorm == fnorm) || fnorm > 1e300) { status = 2; break; }
-        if (fnorm < a.dc_abstol) { status = 0; break; }
+        std::vector<int> keep;
+        for (int sm : act) {
+          fnorm[sm] = h_red[(size_t)sm * 8];
+          if (!(fnorm[sm] == fnorm[sm]) || fnorm[sm] > 1e300) status[sm] = 2;
+          else if (fnorm[sm] < a.dc_abstol) status[sm] = 0;
+          else keep.push_back(sm);
+        }
+        act.swap(keep);
+        if (act.empty()) break;
       }
       if (it == maxit) break;
-      SPDBG("norm ok");
       bool fresh = false;
-      if (!plan[which].valid) { int rc = sparse_plan_from_current(which); if (rc != CH_OK) { status = 2; break; } d = sparse_dev(which); fresh = true; }
-      SPDBG("plan ready");
-      const bool damp = a.mode == MODE_DC && a.dv_max > 0.0 && (!A.mos_hdev.empty() || A.wide);
-      double scale = 1.0;
-      bool failed = false;
-      for (int attempt = 0; attempt < 2; ++attempt) {
-        hipLaunchKernelGGL(sp_lu_solve_kernel, dim3(1), dim3(1024), 0, st, d);
-        if (damp) {
-          hipLaunchKernelGGL(sp_norms_kernel, dim3(1), dim3(1024), 0, st, a, d, 1);
-          int rc = sp_sync(); if (rc != CH_OK) return rc;
-          if (!h_flag[0] && h_red[1] > a.dv_max) scale = a.dv_max / h_red[1];
+      if (!plan[which].valid) { int rc = sparse_plan_from_current(which, act[0]); if (rc != CH_OK) { for (int sm : act) status[sm] = 2; act.clear(); break; } fresh = true; }
+      std::vector<int> work = act;   // samples whose factorisation is still to be done in this iteration
+      for (int attempt = 0; attempt < 2 && !work.empty(); ++attempt) {
+        for (int sm : work) {
+          const SparseDev d = sparse_dev(which, sm);
+          hipLaunchKernelGGL(sp_lu_solve_kernel, dim3(1), dim3(1024), 0, st, d);
+          if (damp) hipLaunchKernelGGL(sp_norms_kernel, dim3(1), dim3(1024), 0, st, a, d, 1);
         }
-        hipLaunchKernelGGL(sp_update_kernel, dim3(1), dim3(1024), 0, st, a, d, scale);  // no-op when the factorisation failed
+        if (damp) {
+          int rc = sp_sync(); if (rc != CH_OK) return rc;
+          for (int sm : work) { scale[sm] = 1.0; const double mx = h_red[(size_t)sm * 8 + 1]; if (!h_flag[(size_t)sm * 2] && mx > a.dv_max) scale[sm] = a.dv_max / mx; }
+        }
+        for (int sm : work) hipLaunchKernelGGL(sp_update_kernel, dim3(1), dim3(1024), 0, st, a, sparse_dev(which, sm), damp ? scale[sm] : 1.0);  // no-op when the factorisation failed
         int rc = sp_sync(); if (rc != CH_OK) return rc;
-        n_launch += 2;
-        if (!h_flag[0]) break;
-        // a static pivot became zero: re-analyse once with the current values (KLU would re-pivot here too)
-        if (fresh || attempt == 1) { failed = true; break; }
-        rc = sparse_plan_from_current(which); if (rc != CH_OK) { failed = true; break; }
-        d = sparse_dev(which); fresh = true;
+        n_launch += 2 * (long)work.size();
+        std::vector<int> failed;
+        for (int sm : work) if (h_flag[(size_t)sm * 2]) failed.push_back(sm);
+        if (failed.empty()) break;
+        // a static pivot became zero: re-analyse once with the current values of the first failing sample (KLU would
+        // re-pivot here too) and redo the failing samples; the others have already taken their step
+        if (fresh || attempt == 1) { for (int sm : failed) status[sm] = 2; work.clear(); act.erase(std::remove_if(act.begin(), act.end(), [&](int q) { return status[q] == 2; }), act.end()); break; }
+        rc = sparse_plan_from_current(which, failed[0]);
+        if (rc != CH_OK) { for (int sm : failed) status[sm] = 2; act.erase(std::remove_if(act.begin(), act.end(), [&](int q) { return status[q] == 2; }), act.end()); break; }
+        fresh = true;
+        work.swap(failed);
       }
-      SPDBG("solved");
-      if (failed) { status = 2; break; }
-      ++iters;
-      if (h_flag[1]) { status = 2; break; }
-      if (a.mode == MODE_TRAN) {
-        const double dn = std::sqrt(h_red[2] / n);
-        if (it == 0) { if (dn <= a.newton_tol || (rate_prev < 0.9 && 2.0 * std::max(rate_prev, 0.02) * dn <= a.newton_tol)) { status = 0; break; } }
-        else { rate_new = dn_prev > 0 ? dn / dn_prev : 0.0; if (dn <= a.newton_tol) { status = 0; break; } }
-        dn_prev = dn;
+      std::vector<int> keep;
+      for (int sm : act) {
+        if (status[sm] == 2) continue;
+        ++iters[sm];
+        if (h_flag[(size_t)sm * 2 + 1]) { status[sm] = 2; continue; }
+        if (a.mode == MODE_TRAN) {
+          const double dn = std::sqrt(h_red[(size_t)sm * 8 + 2] / n);
+          bool conv = false;
+          if (it == 0) conv = dn <= a.newton_tol || (rate_prev[sm] < 0.9 && 2.0 * std::max(rate_prev[sm], 0.02) * dn <= a.newton_tol);
+          else { rate_new[sm] = dn_prev[sm] > 0 ? dn / dn_prev[sm] : 0.0; conv = dn <= a.newton_tol; }
+          dn_prev[sm] = dn;
+          if (conv) { status[sm] = 0; continue; }
+        }
+        keep.push_back(sm);
+      }
+      act.swap(keep);
+    }
+    for (int sm : todo) {
+      if (a.mode == MODE_TRAN && status[sm] == 0) sp_rate_v[sm] = iters[sm] >= 2 ? std::min(1.0, std::max(rate_new[sm], 1e-4)) : std::min(1.0, rate_prev[sm] * 1.5);
+      hipLaunchKernelGGL(sp_commit_kernel, dim3(1), dim3(1024), 0, st, a, sparse_dev(which, sm), (a.mode == MODE_TRAN) ? 0 : 1);
+    }
+    int rc = sp_sync(); if (rc != CH_OK) return rc;
+    n_launch += (long)todo.size();
+    for (int sm : todo) {
+      sp_status_v[sm] = status[sm];
+      if (status[sm] != 0) ++out.n_fail;
+      if (status[sm] == 2) ++out.n_singular;
+      out.max_iters = std::max(out.max_iters, iters[sm]); out.sum_iters += iters[sm]; out.sum_block_iters += iters[sm]; out.fnorm = std::max(out.fnorm, fnorm[sm]);
+      const double* r = h_red + (size_t)sm * 8;
+      if (a.mode == MODE_TRAN && r[7] > 0) {
+        out.errk = std::max(out.errk, a.ck * std::sqrt(r[4] / r[7])); out.errkm1 = std::max(out.errkm1, a.ckm1 * std::sqrt(r[5] / r[7])); out.errkp1 = std::max(out.errkp1, a.ckp1 * std::sqrt(r[6] / r[7]));
       }
     }
-    if (a.mode == MODE_TRAN && status == 0) sp_rate = iters >= 2 ? std::min(1.0, std::max(rate_new, 1e-4)) : std::min(1.0, rate_prev * 1.5);
-    SPDBG("commit");
-    hipLaunchKernelGGL(sp_commit_kernel, dim3(1), dim3(1024), 0, st, a, d, (a.mode == MODE_TRAN) ? 0 : 1);
-    int rc = sp_sync(); if (rc != CH_OK) return rc;
-    n_launch += 1;
-    out.n_fail = status != 0; out.n_singular = status == 2; out.max_iters = iters; out.sum_iters = iters; out.sum_block_iters = iters; out.fnorm = fnorm;
-    const double nd_ = h_red[7];
-    if (a.mode == MODE_TRAN && nd_ > 0) { out.errk = a.ck * std::sqrt(h_red[4] / nd_); out.errkm1 = a.ckm1 * std::sqrt(h_red[5] / nd_); out.errkp1 = a.ckp1 * std::sqrt(h_red[6] / nd_); }
-    sp_status = status;
     return CH_OK;
   }
-  int sp_status = 0;
 
   // host_active: host copy of the per-block active mask given to the kernel (DC restart passes, ch_eval), or null
   int run_newton(const NewtonArgs& a, const unsigned char* host_active, Summary& out) {
-    if (path == 2) return run_sparse(a, out);
+    if (path == 2) return run_sparse(a, host_active, out);
     hipStream_t st = ctx->stream;
     const int nblk = A.n_comp * S;
     // kernel duration is sampled with HIP events on 1 launch in 4 (the events cost host time on every step)
@@ -833,7 +874,7 @@ struct ch_circuit {
         if (rc != CH_OK) return rc;
       }
       if (stt) { stt->n_block_iters += sm.sum_block_iters; stt->nnonliniter += sm.sum_iters; stt->nf += sm.sum_iters; stt->njacs += sm.sum_iters; stt->nfactors += sm.sum_iters; stt->nsolve += sm.sum_iters; }
-      if (path == 2) { for (int b = 0; b < nblk; ++b) bo[b].status = sp_status; }
+      if (path == 2) { for (int b = 0; b < nblk; ++b) bo[b].status = sp_status_v[b % S]; }
       else if (host_reduce) std::memcpy(bo.data(), h_out, nblk * sizeof(BlockOut)); else HIPCHK(hipMemcpy(bo.data(), d_out.p, nblk * sizeof(BlockOut), hipMemcpyDeviceToHost));
       n_active = 0;
       for (int b = 0; b < nblk; ++b) if (active[b]) { if (bo[b].status == 0) active[b] = 0; else ++n_active; }
@@ -1259,9 +1300,9 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
   if (c->path == 2) {
     const size_t nnz = c->h_colidx.size();
     std::vector<double> av(nnz), fv(A.n_unk), qv(A.n_unk);
-    (void)hipMemcpy(av.data(), c->sp_Aval.p, nnz * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(fv.data(), c->sp_F.p, fv.size() * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(qv.data(), c->sp_Q.p, qv.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(av.data(), c->sp_Aval.p + (size_t)sample * nnz, nnz * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(fv.data(), c->sp_F.p + (size_t)sample * A.n_unk, fv.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(qv.data(), c->sp_Q.p + (size_t)sample * A.n_unk, qv.size() * sizeof(double), hipMemcpyDeviceToHost);
     for (int u = 0; u < A.n_unk; ++u) {
       const int ri = A.unk_mna[u]; has[ri] = 1;
       if (F_out) F_out[ri] = fv[u];

@@ -194,6 +194,7 @@ struct SparseDev {
   const int* lrow_ptr; const int* l_pos; const int* l_k; const int* l_upd_ptr; const int* upd_dst; const int* upd_src;
   const int* urow_ptr; const int* u_pos; const int* u_col;
   int n, nnz, nnz_lu, n_lvl, n_ulvl, n_dev;
+  int s; long xofs;                // sample handled by this launch; its offset s*n inside a slot of the state ring
   int stride, q_ofs, c_ofs, wide;  // stamp record layout (40/4/16 narrow, 144/8/64 with compiled Verilog-A devices)
   // work arrays
   double* stage; double* Aval; double* Cval; double* LUv; double* F; double* Q; double* rhs; double* y; double* dx;
@@ -207,12 +208,12 @@ struct SparseDev {
 __global__ void sp_predict_kernel(const NewtonArgs a, const SparseDev d) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n) return;
-  const double x0 = a.X[(long)a.hist_slot[0] * a.slot_stride + i];
+  const double x0 = a.X[(long)a.hist_slot[0] * a.slot_stride + d.xofs + i];
   double p = x0, h = 0.0;
   if (a.mode == MODE_TRAN) {
     p = 0.0;
-    for (int j = 0; j < a.npred; ++j) p += a.wpred[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + i];
-    for (int j = 1; j <= a.k; ++j) h += a.alpha[j] * a.Qh[(long)a.hist_slot[j - 1] * a.slot_stride + i];
+    for (int j = 0; j < a.npred; ++j) p += a.wpred[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + d.xofs + i];
+    for (int j = 1; j <= a.k; ++j) h += a.alpha[j] * a.Qh[(long)a.hist_slot[j - 1] * a.slot_stride + d.xofs + i];
   }
   d.xpred[i] = p; d.xcur[i] = p; d.hq[i] = h; d.qn[i] = 0.0;
   d.w[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
@@ -222,7 +223,9 @@ __global__ void sp_predict_kernel(const NewtonArgs a, const SparseDev d) {
 __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const SparseDev d) {
   const int dev = blockIdx.x * blockDim.x + threadIdx.x;
   if (dev >= d.n_dev) return;
-  const double* kvl = a.inline_vals ? nullptr : a.kv;
+  const int sm = d.s;
+  const double* kvl = a.inline_vals ? nullptr : a.kv + (long)(a.Ssrc > 1 ? sm : 0) * a.nk;
+  const double* svg = a.srcv + (long)(a.Ssrc > 1 ? sm : 0) * a.nsrc;
   const int kind = a.dkind[dev];
   const int* tm = a.dterm + NTERM * dev;
   double v[4];
@@ -234,10 +237,11 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
     else v[k] = kvl[-t - 1];
   }
   const int hd = a.dhdev[dev];
-  const long pi = (long)hd * a.Spar;
+  const long pi = (long)hd * a.Spar + (a.Spar > 1 ? sm : 0);
   const double m = a.dmult[pi];
+  const double gmin = a.gmin_s[a.Sgmin > 1 ? sm : 0];
   double* st_final = d.stage + (size_t)dev * d.stride;
-  auto srcval = [&](int si) { if (a.inline_vals) { double r = 0.0; for (int q = 0; q < KV_INLINE; ++q) if (q == a.nk + si) r = a.vals_inline[q]; return r; } return a.srcv[si]; };
+  auto srcval = [&](int si) { if (a.inline_vals) { double r = 0.0; for (int q = 0; q < KV_INLINE; ++q) if (q == a.nk + si) r = a.vals_inline[q]; return r; } return svg[si]; };
   if (kind == K_VA) {
     double vv[NTERM];
     for (int k = 0; k < NTERM; ++k) {
@@ -246,16 +250,16 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
       else if (a.inline_vals) { double kvv = 0.0; for (int q = 0; q < KV_INLINE; ++q) if (q == -t - 1) kvv = a.vals_inline[q]; vv[k] = kvv; }
       else vv[k] = kvl[-t - 1];
     }
-    const va::Env env{a.temp_s[0] + 273.15, a.gmin_s[0]};
-    va_gen::stamp(a.dcls_local[dev], a.vapar + a.dsrc[dev], vv, env, m, st_final);
+    const va::Env env{a.temp_s[a.Stemp > 1 ? sm : 0] + 273.15, gmin};
+    va_gen::stamp(a.dcls_local[dev], a.vapar + (long)sm * a.va_stride + a.dsrc[dev], vv, env, m, st_final);
     return;
   }
   double tmp40[40];
   double* st = d.wide ? tmp40 : st_final;
   if (kind == K_MOS) {
-    const B4Col P = b4_col(a.mosp, (long)a.dcls[dev] * a.Smos);
+    const B4Col P = b4_col(a.mosp, (long)a.dcls[dev] * a.Smos + (a.Smos > 1 ? sm : 0));
     double o[40];
-    b4_device(P, v[0], v[1], v[2], v[3], a.gmin_s[0], o);
+    b4_device(P, v[0], v[1], v[2], v[3], gmin, o);
     for (int j = 0; j < 40; ++j) st[j] = m * o[j];
     if (d.wide) widen_stamp(st, st_final);
     return;
@@ -397,16 +401,16 @@ __global__ __launch_bounds__(1024) void sp_commit_kernel(const NewtonArgs a, con
   double e2k = 0, e2m = 0, e2p = 0, nd = 0;
   for (int i = t; i < d.n; i += 1024) {
     const double xn = d.xcur[i];
-    a.X[(long)a.cand_slot * a.slot_stride + i] = xn;
-    a.Qh[(long)a.cand_slot * a.slot_stride + i] = use_q_of_eval ? d.Q[i] : d.qn[i];
-    if (a.obs_row) { const int ob = a.unk_obs[i]; if (ob >= 0) a.obs_row[ob] = xn; }
+    a.X[(long)a.cand_slot * a.slot_stride + d.xofs + i] = xn;
+    a.Qh[(long)a.cand_slot * a.slot_stride + d.xofs + i] = use_q_of_eval ? d.Q[i] : d.qn[i];
+    if (a.obs_row) { const int ob = a.unk_obs[i]; if (ob >= 0) a.obs_row[(long)ob * a.S + d.s] = xn; }
     if (a.mode == MODE_TRAN && (a.dmask[i] & 1)) {
-      const double x0 = a.X[(long)a.hist_slot[0] * a.slot_stride + i];
+      const double x0 = a.X[(long)a.hist_slot[0] * a.slot_stride + d.xofs + i];
       const double w = 1.0 / (a.reltol * fmax(fabs(x0), fabs(xn)) + a.abstol);
       nd += 1.0;
       double tt = (xn - d.xpred[i]) * w; e2k += tt * tt;
-      if (a.nkm1 > 0) { double p = 0.0; for (int j = 0; j < a.nkm1; ++j) p += a.wkm1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + i]; tt = (xn - p) * w; e2m += tt * tt; }
-      if (a.nkp1 > 0) { double p = 0.0; for (int j = 0; j < a.nkp1; ++j) p += a.wkp1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + i]; tt = (xn - p) * w; e2p += tt * tt; }
+      if (a.nkm1 > 0) { double p = 0.0; for (int j = 0; j < a.nkm1; ++j) p += a.wkm1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + d.xofs + i]; tt = (xn - p) * w; e2m += tt * tt; }
+      if (a.nkp1 > 0) { double p = 0.0; for (int j = 0; j < a.nkp1; ++j) p += a.wkp1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + d.xofs + i]; tt = (xn - p) * w; e2p += tt * tt; }
     }
   }
   s0[t] = e2k; s1[t] = e2m; s2[t] = e2p; s3[t] = nd;

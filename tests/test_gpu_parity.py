@@ -443,3 +443,35 @@ def test_monte_carlo_1024_samples_lockstep_gate(E):
     assert rc == 0 and v.shape == (1, 5, S)
     assert np.max(np.abs(v[0] - np.array(DFF_CHECK_Q)[:, None])) < 1e-3
     assert st["n_block_iters"] >= S * st["naccept"]
+
+
+def test_sparse_path_batched_samples_match_per_sample_oracle(E, O):
+    """A sweep over a circuit whose Jacobian block is too large for one CU: the samples share the symbolic plan of the
+    sparse LU and are solved in one batched call; every sample must equal its own oracle run."""
+    c = rc_ladder(200)
+    s_r, s_c = c.slot("r100", "r"), c.slot("c150", "c")
+    rs, cs = [500.0, 1e3, 5e3, 2e4], [1e-12, 4e-12, 1e-12, 2.5e-13]
+    eng = E(c)
+    eng.set_samples(4)
+    eng.set_params([s_r, s_c], [rs, cs])
+    sv = np.array([1e-8, 1e-7, 4e-7, 1e-6])
+    rc, t, v, xf, st = eng.tran(0.0, 1e-6, tran_opts(abstol=1e-9, reltol=1e-6, saveat=sv))
+    assert rc == 0 and eng.info()["path"] == 2 and v.shape[2] == 4
+    for k in range(4):
+        o = O(c)
+        o.set_param(s_r, rs[k])
+        o.set_param(s_c, cs[k])
+        rco, to, vo, _, _ = o.tran(0.0, 1e-6, tran_opts(abstol=1e-9, reltol=1e-6, saveat=sv))
+        vo = vo if vo.ndim == 2 else vo[:, :, 0]
+        assert rco == 0 and np.max(np.abs(v[:, :, k] - vo)) < 1e-4, k
+    assert np.abs(v[:, :, 0] - v[:, :, 3]).max() > 1e-3          # the samples really differ
+    # DC sweep of the source value on the same path: every node follows its sample's source
+    c2 = rc_ladder(200)
+    sl = c2.slot("vin", "dc")
+    e2 = E(c2)
+    e2.set_samples(3)
+    e2.set_params([sl], [[0.5, 1.0, 2.0]])
+    rc, x, status, st = e2.dc(dc_opts(abstol=1e-12))
+    assert rc == 0 and e2.info()["path"] == 2
+    for k, vv in enumerate((0.5, 1.0, 2.0)):
+        assert np.nanmax(np.abs(x[k][:201] - vv)) < 1e-9
