@@ -367,6 +367,65 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
     // ---- prologue: stage lists / known values / BSIM4 columns in LDS, predictor and history term ----
     // All global loads of one level are issued before any is consumed (batches of 8 per thread), so
     // the prologue costs a few memory latencies instead of one per element.
+    constexpr int PB = 18;  // 8 DFF classes x 137 doubles / 64 lanes = 17.1: one batch of loads in flight
+    const long scol = a.Smos > 1 ? s : 0;
+    const bool fast = nthr == 64 && bm.mc_n <= 8 && cm.blob_ints <= 8 * 64 && bm.mc_n * B4I_COUNT <= PB * 64 && nc <= 64;
+    if (fast) {
+      // One wave, everything fits one batch per lane: ALL global loads of the prologue (class blob, BSIM4 columns of the
+      // block's classes, state history) are issued back to back before the first one is consumed — one memory latency
+      // instead of three dependent ones (the class ids come from the BlockMeta registers, not from LDS).
+      const int* src = a.blob + cm.blob_ofs;
+      const int nb = cm.blob_ints, total = bm.mc_n * B4I_COUNT;
+      int bv[8]; double pv[PB]; double x0 = 0.0, xv[7], qv[5];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = tid + u * 64; bv[u] = src[i < nb ? i : nb - 1]; }
+      if (total > 0) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+          const int e0 = tid + u * 64, e = e0 < total ? e0 : total - 1;
+          const int j = e / B4I_COUNT, i = e - j * B4I_COUNT;
+          int cls = bm.mc[0];
+#pragma unroll
+          for (int q = 1; q < 8; ++q) cls = j == q ? bm.mc[q] : cls;
+          pv[u] = a.mosp[((long)cls * a.Smos + scol) * (long)B4I_COUNT + i];
+        }
+      }
+      const int iu = tid < nc ? tid : 0;
+      x0 = X0[iu];
+      if (a.mode == MODE_TRAN) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) xv[j] = a.X[(long)a.hist_slot[j < a.npred ? j : 0] * a.slot_stride + sofs + iu];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) qv[j] = a.Qh[(long)a.hist_slot[j < a.k ? j : 0] * a.slot_stride + sofs + iu];
+      }
+      if (a.inline_vals) {
+#pragma unroll
+        for (int i = 0; i < KV_INLINE; ++i) if (tid == i && i < a.nk + a.nsrc) kvl[i] = a.vals_inline[i];  // kvl and svl are contiguous
+      } else {
+        const double* kg = a.kv + (long)(a.Ssrc > 1 ? s : 0) * a.nk;
+        const double* sg = a.srcv + (long)(a.Ssrc > 1 ? s : 0) * a.nsrc;
+        for (int i = tid; i < a.nk; i += nthr) kvl[i] = kg[i];
+        for (int i = tid; i < a.nsrc; i += nthr) svl[i] = sg[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = tid + u * 64; if (i < nb) mptr[i] = bv[u]; }
+      if (total > 0) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u) { const int e = tid + u * 64; if (e < total) pl[e] = pv[u]; }
+      }
+      if (tid < nc) {
+        double p = x0, h = 0.0;
+        if (a.mode == MODE_TRAN) {
+          p = 0.0;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) p += (j < a.npred ? a.wpred[j + 1] : 0.0) * xv[j];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) h += (j < a.k ? a.alpha[j + 1] : 0.0) * qv[j];
+        }
+        xp[tid] = p; xl[tid] = p; hq[tid] = h; qn[tid] = 0.0;
+        wv[tid] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
+      }
+    } else {
     {
       const int nmc = bm.mc_n, mco = bm.mc_ofs;
       if (nmc <= 8) {
@@ -396,8 +455,6 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       }
       __syncthreads();  // mcl visible
       const int total = nmc * B4I_COUNT;
-      const long scol = a.Smos > 1 ? s : 0;
-      constexpr int PB = 18;  // 8 DFF classes x 137 doubles / 64 lanes = 17.1: one batch of loads in flight
       if (total > 0) for (int base = tid; base < total; base += nthr * PB) {
         double v[PB];
 #pragma unroll
@@ -427,6 +484,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       }
       xp[i] = p; xl[i] = p; hq[i] = h; qn[i] = 0.0;
       wv[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
+    }
     }
     if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 1; s_ctl[2] = 0; }
     __syncthreads();
