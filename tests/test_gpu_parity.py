@@ -475,3 +475,43 @@ def test_sparse_path_batched_samples_match_per_sample_oracle(E, O):
     assert rc == 0 and e2.info()["path"] == 2
     for k, vv in enumerate((0.5, 1.0, 2.0)):
         assert np.nanmax(np.abs(x[k][:201] - vv)) < 1e-9
+
+
+GPU_SHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+from cedarsim_jl_amd import Circuit, CircuitSweep, ProductSweep, dc, gather_sharded
+dist.init_process_group("gloo")           # two ranks share the one GPU of this box; on a node every rank has its own GPU + RCCL
+rank, world = dist.get_rank(), dist.get_world_size()
+
+def build(r1=100.0, r2=100.0):
+    c = Circuit(); c.V("V", "vcc", 0, dc=1.0); c.R("R1", "vcc", "mid", r1); c.R("R2", "mid", 0, r2)
+    return c
+
+sweep = ProductSweep(r1=[100.0 * i for i in range(1, 11)], r2=[100.0 * j for j in range(1, 11)])
+cs = CircuitSweep(build, sweep, rank=rank, world=world)
+sols = dc(cs)                                   # this rank's contiguous shard, one batched GPU solve
+local = np.array([[s["V.i"][0], float(rank)] for s in sols])
+full = gather_sharded(local, len(cs), rank, world)
+want = np.array([-1.0 / (p["r1"] + p["r2"]) for p in cs])
+assert full.shape == (100, 2) and np.allclose(full[:, 0], want, rtol=1e-9), np.abs(full[:, 0] - want).max()
+assert np.all(full[:50, 1] == 0) and np.all(full[50:, 1] == 1)
+if rank == 0: print("GPU_SHARD_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_sweep_two_ranks_on_the_gpu(tmp_path):
+    """SURVEY §8(e) end to end on real hardware: two processes, each solves its contiguous shard of a 10x10 sweep
+    (test/sweep.jl:326-340) on the GPU through the C-ABI, one all_gather of the results at the end."""
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text(GPU_SHARD_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", OMP_NUM_THREADS="1", CEDARHIP_USE_LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29537", str(script), root], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GPU_SHARD_OK" in r.stdout
