@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -246,6 +247,7 @@ struct ch_circuit {
   void set_err(const std::string& s) { ctx->err = s; }
 
   ~ch_circuit() {
+    if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);  // a polled launch may still be retiring
     if (g_arena == &arena) g_arena = nullptr;
     if (h_sum) (void)hipHostFree(h_sum);
     if (h_out) (void)hipHostFree(h_out);
@@ -482,6 +484,7 @@ struct ch_circuit {
     if (host_reduce && h_out_n < (size_t)A.n_comp * S) {
       if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; h_out_n = 0; }
       HIPCHK(hipHostMalloc((void**)&h_out, (size_t)A.n_comp * S * sizeof(BlockOut), hipHostMallocMapped));
+      std::memset(h_out, 0, (size_t)A.n_comp * S * sizeof(BlockOut));   // sequence numbers start at 1
       h_out_n = (size_t)A.n_comp * S;
     }
     HIPCHK(d_active.alloc((size_t)A.n_comp * S));
@@ -759,8 +762,8 @@ struct ch_circuit {
     if (path == 2) return run_sparse(a, host_active, out);
     hipStream_t st = ctx->stream;
     const int nblk = A.n_comp * S;
-    // kernel duration is sampled with HIP events on 1 launch in 4 (the events cost host time on every step)
-    const bool timed = (n_launch & 3) == 0;
+    // kernel duration is sampled with HIP events on 1 launch in 8 (the events cost host time on every step)
+    const bool timed = (n_launch & 7) == 0;
     if (timed) HIPCHK(hipEventRecord(ev0, st));
     if (A.wide) {
       if (lu_variant == 16) hipLaunchKernelGGL((newton_block_kernel<16, true>), dim3(nblk), dim3(block_threads), lds_bytes, st, a);
@@ -773,7 +776,9 @@ struct ch_circuit {
     else hipLaunchKernelGGL(newton_block_kernel<0>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
     if (timed) HIPCHK(hipEventRecord(ev1, st));
     if (!host_reduce) hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 9 * 256 * sizeof(double), st, a);
-    // the host thread has nothing else to do: poll for completion instead of sleeping on an interrupt
+    // the host thread has nothing else to do: poll for completion instead of sleeping on an interrupt.
+    // (Watching the block records in mapped memory for a per-launch sequence number instead of the stream signal was
+    // tried: the system-scope release each block then needs costs ~28 us per launch; profiles/r01_notes.md.)
     {
       hipError_t q = hipErrorNotReady;
       for (int spin = 0; spin < 200000 && q == hipErrorNotReady; ++spin) q = hipStreamQuery(st);
