@@ -515,3 +515,28 @@ def test_sharded_sweep_two_ranks_on_the_gpu(tmp_path):
                         "--master-port", "29537", str(script), root], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GPU_SHARD_OK" in r.stdout
+
+
+def test_large_batch_uses_the_device_side_reduction(E):
+    """More than 4096 blocks: the per-block records are reduced by `reduce_blocks_kernel` instead of the host.  4608
+    samples of one DFF with two distinct parameter sets: the halves must agree internally to round-off and with a
+    2-sample run of the same two sets (host-reduced path)."""
+    c = dff_array(1)
+    slot = c.slot("nfet_06v0", "vth0")
+    base = c.models[c.model_names.index("nfet_06v0")][B4.PARAM_INDEX["vth0"]]
+    S = 4608
+    vals = np.where(np.arange(S) % 2 == 0, base, 1.03 * base)[None, :]
+    opts = lambda: tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14), saveat=np.array(DFF_CHECK_TIMES))  # noqa: E731
+    e = E(c)
+    e.set_samples(S)
+    e.set_params([slot], vals)
+    rc, t, v, xf, st = e.tran(0.0, 7e-7, opts())
+    assert rc == 0 and v.shape == (1, 5, S)
+    assert np.max(np.abs(v[0] - np.array(DFF_CHECK_Q)[:, None])) < 1e-3
+    assert np.abs(v[0][:, 0::2] - v[0][:, 0:1]).max() < 1e-12 and np.abs(v[0][:, 1::2] - v[0][:, 1:2]).max() < 1e-12
+    e2 = E(c)
+    e2.set_samples(2)
+    e2.set_params([slot], [[base, 1.03 * base]])
+    rc2, t2, v2, _, st2 = e2.tran(0.0, 7e-7, opts())
+    assert rc2 == 0 and st2["naccept"] == st["naccept"] and st2["nreject"] == st["nreject"]
+    assert np.abs(v2[0] - v[0][:, :2]).max() < 1e-9
