@@ -78,6 +78,21 @@ class Solution:
                     return c.dev_par[i][0] * np.gradient(v, self.t)  # post-processed derivative
         raise KeyError(name)
 
+    def op(self, dev_name, index=-1, ctx=None):
+        """Operating-point observables of a compiled Verilog-A instance at saved point `index` — `sol[sys.x1.gm]` for the
+        variables a module declares with (* desc *) (src/vasim.jl:742-753).  Evaluated on the GPU from the node voltages."""
+        from .engine import default_context
+        c = self.circuit
+        name = str(dev_name).lower()
+        if name not in getattr(c, "va_instances", {}):
+            raise KeyError("'%s' is not a compiled Verilog-A instance" % dev_name)
+        i = c.dev_names.index(name)
+        mid, ofs = c.dev_ipar[i]
+        mod, _ = c.va_instances[name]
+        v = [float(self._node_series(n)[index]) for n in c.dev_node[i][:len(mod.nodes)]]
+        par = c.va_par[ofs:ofs + 2 * len(mod.params)]
+        return (ctx or default_context()).va_opvars(mid, par, v, c.temp + 273.15, c.gmin)
+
     def default_name_map(self):
         """{solution key: column name} for every observed top-level node voltage — default_name_map (src/util.jl:239-260):
         the `node_` prefix is dropped and ground aliases are left out."""

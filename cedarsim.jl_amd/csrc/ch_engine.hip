@@ -1612,6 +1612,27 @@ int ch_va_eval(ch_ctx* ctx, int32_t id, const double* par, const double* v, doub
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return CH_ERR_DEVICE; }
   return CH_OK;
 }
+int32_t ch_va_n_opvars(int32_t id) { return (id >= 0 && id < va_gen::N_MODULES) ? va_gen::N_OPVARS[id] : 0; }
+const char* ch_va_opvar_name(int32_t id, int32_t k) { return (id >= 0 && id < va_gen::N_MODULES && k >= 0 && k < va_gen::N_OPVARS[id]) ? va_gen::OPNAMES[id][k] : nullptr; }
+int ch_va_opvars(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* op_out) {
+  if (!ctx || !par || !v || !op_out || id < 0 || id >= va_gen::N_MODULES) return CH_ERR_INVALID;
+  const int nop = va_gen::N_OPVARS[id];
+  if (nop == 0) return CH_OK;
+  (void)hipSetDevice(ctx->device);
+  const va_gen::ModuleInfo& mi = va_gen::MODULES[id];
+  double *dp = nullptr, *dv = nullptr, *dop = nullptr;
+  if (hipMalloc((void**)&dp, (size_t)std::max(1, 2 * mi.n_params) * sizeof(double)) != hipSuccess || hipMalloc((void**)&dv, NTERM * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&dop, (size_t)nop * sizeof(double)) != hipSuccess) return CH_ERR_DEVICE;
+  double vv[NTERM] = {0}; for (int k = 0; k < mi.n_nodes; ++k) vv[k] = v[k];
+  (void)hipMemcpy(dp, par, (size_t)2 * mi.n_params * sizeof(double), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dv, vv, sizeof(vv), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(va_opvars_kernel, dim3(1), dim3(64), 0, ctx->stream, (int)id, (const double*)dp, (const double*)dv, temperature_k, gmin, dop);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(op_out, dop, (size_t)nop * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dp); (void)hipFree(dv); (void)hipFree(dop);
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return CH_ERR_DEVICE; }
+  return CH_OK;
+}
 const char* ch_version(void) { return "cedarhip 0.1 (gfx950; fused block Newton)"; }
 
 }  // extern "C"

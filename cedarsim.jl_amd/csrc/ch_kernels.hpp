@@ -933,6 +933,14 @@ __global__ void va_eval_kernel(int mod, const double* P, const double* v, double
   for (int k = 0; k < 144; ++k) st[k] = out[k];
 }
 
+__global__ void va_opvars_kernel(int mod, const double* P, const double* v, double temp_k, double gmin, double* op) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double vv[NTERM];
+  for (int k = 0; k < NTERM; ++k) vv[k] = v[k];
+  const va::Env env{temp_k, gmin};
+  va_gen::opvars(mod, P, vv, env, op);
+}
+
 // y = x - y (AC right-hand side b = F(src) - F(src + ac))
 __global__ void axpby_kernel(double* y, const double* x, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -22,7 +22,7 @@ EXPORTS = [
     "ch_result_n_times", "ch_result_times", "ch_result_values", "ch_result_final_state", "ch_result_stats",
     "ch_result_status", "ch_result_free", "ch_eval", "ch_ac", "ch_noise", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
     "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64", "ch_va_n_modules", "ch_va_find", "ch_va_module_name", "ch_va_module_info",
-    "ch_va_node_name", "ch_va_param_name", "ch_va_eval",
+    "ch_va_node_name", "ch_va_param_name", "ch_va_eval", "ch_va_n_opvars", "ch_va_opvar_name", "ch_va_opvars",
 ]
 
 _lib = None
@@ -78,6 +78,10 @@ def load_library():
     L.ch_va_param_name.argtypes = [C.c_int32, C.c_int32]
     L.ch_va_param_name.restype = C.c_char_p
     L.ch_va_eval.argtypes = [vp, C.c_int32, _pf64, _pf64, C.c_double, C.c_double, _pf64]
+    L.ch_va_n_opvars.argtypes = [C.c_int32]
+    L.ch_va_opvar_name.argtypes = [C.c_int32, C.c_int32]
+    L.ch_va_opvar_name.restype = C.c_char_p
+    L.ch_va_opvars.argtypes = [vp, C.c_int32, _pf64, _pf64, C.c_double, C.c_double, _pf64]
     L.ch_version.restype = C.c_char_p
     L.ch_bench_triad.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     L.ch_bench_fp64.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
@@ -122,6 +126,18 @@ class Context:
         if rc != 0:
             raise RuntimeError("ch_va_eval failed: %s" % self.last_error())
         return out
+
+    def va_opvars(self, module_id, par_and_given, v_nodes, temperature_k=300.15, gmin=1e-12):
+        """{name: value} of the (* desc *) observables of a compiled module at the given node voltages (on the GPU)."""
+        n = self.L.ch_va_n_opvars(int(module_id))
+        p = np.ascontiguousarray(par_and_given, dtype=np.float64)
+        v = np.zeros(8)
+        v[:len(v_nodes)] = v_nodes
+        out = np.zeros(max(1, n))
+        rc = self.L.ch_va_opvars(self.h, int(module_id), _p(p), _p(v), float(temperature_k), float(gmin), _p(out))
+        if rc != 0:
+            raise RuntimeError("ch_va_opvars failed: %s" % self.last_error())
+        return {self.L.ch_va_opvar_name(int(module_id), k).decode(): float(out[k]) for k in range(n)}
 
     def triad_gbps(self, n_doubles=1 << 27, iters=5):
         """Measured STREAM-triad bandwidth of this GPU in GB/s (measurement utility)."""

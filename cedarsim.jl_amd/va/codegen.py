@@ -411,6 +411,8 @@ class ModuleGen:
                 raise VAError("unknown access function %s" % acc)
             rhs = st[3]
             is_noise = rhs[0] == "call" and rhs[1] in ("white_noise", "flicker_noise")
+            if ctx.get("opvars"):
+                return []
             if ctx.get("noise"):
                 # noise pass: `I(a,b) <+ white_noise(pwr, name)` / `flicker_noise(pwr, exp, name)` become records
                 # (src/va_env.jl:92-101: the power is an observable, the source an epsilon of the linearisation)
@@ -593,6 +595,23 @@ class ModuleGen:
                 self.dual = self.dual_saved
             out.append("  return n_;")
             out.append("}")
+        # operating-point pass: the analog block over plain doubles; the variables declared with a (* desc *) attribute are
+        # the module's observables (src/vasim.jl:742-753, 841-843)
+        self.op_names = [nm for nm in m.var_desc if vars_.get(nm) in ("real", "dual", "int")]
+        if self.op_names:
+            out.append("VA_HD_NOINLINE void opvars(const double* P, const double* V, const va::Env& env, double* op) {")
+            out += param_decls + var_decls("double")
+            out.append("  (void)env; (void)V; (void)P;")
+            octx = {"vars": {k: ("real" if t == "dual" else t) for k, t in vars_.items()}, "S": "double", "noise": True, "opvars": True}
+            saved, self.dual = self.dual, set()
+            try:
+                for st in m.analog:
+                    out += self.stmt(st, octx, 1)
+            finally:
+                self.dual = saved
+            for k, nm in enumerate(self.op_names):
+                out.append("  op[%d] = (double)v_%s;" % (k, nm))
+            out.append("}")
         out.append("}  // namespace m_%s" % m.name)
         return out
 
@@ -610,6 +629,11 @@ def generate_header(modules, source_tag=""):
         m = g.m
         out.append("static const char* const nodes_%s[] = {%s};" % (m.name, ", ".join('"%s"' % n for n in m.nodes) or '""'))
         out.append("static const char* const params_%s[] = {%s};" % (m.name, ", ".join('"%s"' % p[0] for p in m.params) or '""'))
+    for g in gens:
+        ops = getattr(g, "op_names", [])
+        out.append("static const char* const opnames_%s[] = {%s};" % (g.m.name, ", ".join('"%s"' % n for n in ops) or '""'))
+    out.append("static const int N_OPVARS[] = {%s};" % (", ".join(str(len(getattr(g, "op_names", []))) for g in gens) or "0"))
+    out.append("static const char* const* const OPNAMES[] = {%s};" % (", ".join("opnames_%s" % g.m.name for g in gens) or "nullptr"))
     out.append("static const int N_MODULES = %d;" % len(gens))
     out.append("static const ModuleInfo MODULES[] = {")
     for g in gens:
@@ -666,6 +690,16 @@ def generate_header(modules, source_tag=""):
         out.append("        st[16 + k * 8 + dir] = m * va::val(I[k].d[0]); st[80 + k * 8 + dir] = m * va::val(Q[k].d[0]);")
         out.append("      }")
         out.append("    } break;")
+    out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
+    out.append("")
+    out.append("// operating-point variables (the (* desc *) observables) of module `mod` at node voltages v")
+    out.append("VA_HD_NOINLINE void opvars(int mod, const double* P, const double* v, const va::Env& env, double* op) {")
+    out.append("  switch (mod) {")
+    for i, g in enumerate(gens):
+        if getattr(g, "op_names", []):
+            out.append("    case %d: m_%s::opvars(P, v, env, op); break;" % (i, g.m.name))
     out.append("    default: break;")
     out.append("  }")
     out.append("}")

@@ -262,7 +262,9 @@ def tokenize(text):
             raise VAError("line %d: unexpected character %r" % (line, text[i]))
         k = m.lastgroup
         v = m.group(k)
-        if k not in ("ws", "attr"):
+        if k == "attr":
+            toks.append(("attr", v, line))   # (* name = value, ... *): kept for `desc` on variable declarations
+        elif k != "ws":
             toks.append((k, v, line))
         line += v.count("\n")
         i = m.end()
@@ -297,7 +299,7 @@ class Module:
         self.params = []      # [(name, type, default_expr, ranges)]
         self.aliases = {}
         self.vars = {}        # name -> type
-        self.var_desc = {}    # observable variables: (* desc *) attributes are dropped by the lexer; kept empty
+        self.var_desc = {}    # observable variables: name -> text of the (* desc = "..." *) attribute on their declaration
         self.functions = {}
         self.branches = {}    # name -> (a, b|None)
         self.analog = []      # analog statements in order
@@ -355,12 +357,28 @@ class Parser:
 
     # -- token helpers --
     def peek(self, k=0):
-        return self.t[self.i + k]
+        j, n = self.i, 0
+        while True:   # attribute instances are transparent to the grammar
+            while self.t[j][0] == "attr":
+                j += 1
+            if n == k:
+                return self.t[j]
+            j += 1
+            n += 1
+
+    def _skip_attrs(self):
+        last = None
+        while self.t[self.i][0] == "attr":
+            last = self.t[self.i][1]
+            self.i += 1
+        return last
 
     def at(self, v):
-        return self.t[self.i][1] == v and self.t[self.i][0] in ("op", "id")
+        tok = self.peek()
+        return tok[1] == v and tok[0] in ("op", "id")
 
     def eat(self, v=None):
+        self._skip_attrs()
         tok = self.t[self.i]
         if v is not None and tok[1] != v:
             raise VAError("line %d: expected %r, found %r" % (tok[2], v, tok[1]))
@@ -368,6 +386,7 @@ class Parser:
         return tok
 
     def ident(self):
+        self._skip_attrs()
         tok = self.t[self.i]
         if tok[0] != "id":
             raise VAError("line %d: expected an identifier, found %r" % (tok[2], tok[1]))
@@ -626,6 +645,7 @@ class Parser:
             self.eat(")")
         self.eat(";")
         while True:
+            attr = self._skip_attrs()
             k, v, line = self.peek()
             if k == "id" and v == "endmodule":
                 self.eat()
@@ -678,8 +698,14 @@ class Parser:
                 self.eat(";")
             elif k == "id" and v in ("real", "integer", "string"):
                 self.eat()
+                desc = None
+                if attr:
+                    md = re.search(r'desc\s*=\s*"([^"]*)"', attr)
+                    desc = md.group(1) if md else None
                 for nm in self.idlist():
                     m.vars[nm] = v
+                    if desc is not None and v != "string":
+                        m.var_desc[nm] = desc   # operating-point observable (src/vasim.jl:742-753)
                 self.eat(";")
             elif k == "id" and v == "branch":
                 self.eat()

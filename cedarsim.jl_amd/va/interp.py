@@ -388,6 +388,7 @@ class Interp:
         for st in m.analog:
             self.ex(st, fr)
         self.structure = list(self.contribs)
+        self.opvars = {nm: val(fr.vals[nm]) for nm in m.var_desc if nm in fr.vals}   # (* desc *) observables
 
         def flat(x):
             x = x if isinstance(x, D) else D(x, [0.0] * n)

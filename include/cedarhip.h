@@ -295,6 +295,12 @@ const char* ch_va_node_name(int32_t id, int32_t k);
 const char* ch_va_param_name(int32_t id, int32_t k);
 int ch_va_eval(ch_ctx*, int32_t id, const double* par_and_given, const double* v_nodes, double temperature_k, double gmin,
                double* st_out);
+/* Operating-point observables of a module: the variables declared with a (* desc = "..." *) attribute
+ * (src/vasim.jl:742-753, 841-843: `observed!(var, DScope(dscope, name))`), evaluated on the GPU at given node voltages. */
+int32_t ch_va_n_opvars(int32_t id);
+const char* ch_va_opvar_name(int32_t id, int32_t k);
+int ch_va_opvars(ch_ctx*, int32_t id, const double* par_and_given, const double* v_nodes, double temperature_k, double gmin,
+                 double* op_out);
 
 /* ---- library/kernel introspection ---- */
 const char* ch_version(void);

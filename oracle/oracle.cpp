@@ -839,6 +839,15 @@ int oracle_va_eval(int mod, const double* par, const double* v, double temperatu
   va_gen::stamp(mod, par, vv, env, 1.0, st);
   return CH_OK;
 }
+int oracle_va_opvars(int mod, const double* par, const double* v, double temperature_k, double gmin, double* op) {
+  if (mod < 0 || mod >= va_gen::N_MODULES) return -1;
+  double vv[8] = {0};
+  for (int k = 0; k < va_gen::MODULES[mod].n_nodes; ++k) vv[k] = v[k];
+  const va::Env env{temperature_k, gmin};
+  va_gen::opvars(mod, par, vv, env, op);
+  return va_gen::N_OPVARS[mod];
+}
+const char* oracle_va_opvar_name(int mod, int k) { return (mod >= 0 && mod < va_gen::N_MODULES && k >= 0 && k < va_gen::N_OPVARS[mod]) ? va_gen::OPNAMES[mod][k] : nullptr; }
 int oracle_va_n_modules(void) { return va_gen::N_MODULES; }
 const char* oracle_va_module_name(int i) { return (i >= 0 && i < va_gen::N_MODULES) ? va_gen::MODULES[i].name : nullptr; }
 

@@ -41,6 +41,9 @@ def lib():
     L.oracle_noise.argtypes = [C.c_void_p, C.POINTER(ChDcOpts), C.c_int, C.c_int, _pf64, _pf64]
     L.oracle_va_eval.argtypes = [C.c_int, _pf64, _pf64, C.c_double, C.c_double, _pf64]
     L.oracle_va_noise.argtypes = [C.c_int, _pf64, _pf64, C.c_double, C.c_double, _pf64]
+    L.oracle_va_opvars.argtypes = [C.c_int, _pf64, _pf64, C.c_double, C.c_double, _pf64]
+    L.oracle_va_opvar_name.argtypes = [C.c_int, C.c_int]
+    L.oracle_va_opvar_name.restype = C.c_char_p
     L.oracle_va_module_name.argtypes = [C.c_int]
     L.oracle_va_module_name.restype = C.c_char_p
     L.oracle_eval.argtypes = [C.c_void_p, _pf64, C.c_double, C.c_double, C.c_int, _pf64, _pf64, _pf64]

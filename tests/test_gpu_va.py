@@ -318,3 +318,29 @@ def test_voltage_contributions_on_the_gpu(E, O):
     rc, x, status, st = E(c).dc(dc_opts(abstol=1e-14))
     assert rc == 0 and x[0][c._n("out") - 1] == pytest.approx(1.0, rel=1e-12)
     assert x[0][c._n("e1.i(p,n)") - 1] == pytest.approx(-1.0 / 50.0, rel=1e-12)
+
+
+def test_operating_point_observables_on_the_gpu(ctx):
+    """`sol.op(dev)` ≙ `sol[sys.dev.var]` for (* desc *) variables: evaluated on the GPU at the DC solution."""
+    c = Circuit()
+    c.V("vd", "d", 0, dc=2.0)
+    c.V("vg", "g", 0, dc=1.7)
+    c.VA("m1", "va_mos1", ["d", "g", 0, 0], {"KP": 2e-4, "W": 2e-6, "L": 1e-6, "VTO": 0.7, "LAMBDA": 0.0})
+    sol = dc(c, abstol=1e-14)
+    op = sol.op("m1")
+    assert op["REGION"] == 2 and op["VOV"] == pytest.approx(1.0, rel=1e-12) and op["IDS"] == pytest.approx(2e-4, rel=1e-12)
+    assert sol["vd.i"][0] == pytest.approx(-(2e-4 + 1e-12 * 2.0), rel=1e-9)
+    if "bsimcmg" in load_modules()[1]:
+        from cedarsim_jl_amd.workloads import cmg_inverter_array
+        import os
+        cards = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "asap7_tt_lvt_cards.json")))["cards"]
+        ci = cmg_inverter_array(1, cards)
+        s2 = dc(ci, abstol=1e-12)
+        opn = s2.op("mneg0")
+        mod, par = ci.va_instances["mneg0"]
+        it = Interp(mod, par, temperature_c=ci.temp, gmin=ci.gmin)
+        it.evaluate({n: float(s2._node_series(k)[0]) for n, k in zip(mod.nodes, ci.dev_node[ci.dev_names.index("mneg0")])})
+        assert set(opn) == set(it.opvars) and len(opn) == 70
+        for k, v in opn.items():
+            assert v == pytest.approx(it.opvars[k], rel=1e-8, abs=1e-30), k
+        assert opn["IDS"] > 1e-6                                    # the n-FET conducts at the switching point

@@ -249,3 +249,32 @@ def test_front_end_rejects_the_reference_parsers_error_cases():
     for f in files:
         with pytest.raises(VAError):
             parse_va_file(f)
+
+
+def test_operating_point_observables_match_interpreter():
+    """Variables declared with (* desc = "..." *) are the module's observables (src/vasim.jl:742-753): generated
+    `opvars` pass (host instantiation) against the interpreter."""
+    import ctypes as C
+    pd = C.POINTER(C.c_double)
+    cases = [("va_mos1", {"TYPE": 1, "KP": 2e-4, "W": 2e-6}, {"d": 1.2, "g": 1.5, "s": 0.0, "b": 0.0}),
+             ("va_mos1", {"TYPE": -1}, {"d": -0.1, "g": -2.0, "s": 0.0, "b": 0.0})]
+    if "bsimcmg" in load_modules()[1]:
+        cases.append(("bsimcmg", {"DEVTYPE": 1, "L": 2.1e-8, "NFIN": 2}, {"d": 0.6, "g": 0.7, "s": 0.0, "e": 0.0, "di": 0.599, "si": 0.001}))
+    for name, params, vb in cases:
+        mid, mod = find_module(name)
+        it = Interp(mod, params, temperature_c=27.0)
+        it.evaluate(vb)
+        P = np.array([float(it.params[p[0]]) if p[1] != "string" else 0.0 for p in mod.params] + [1.0 if p[0] in it.given else 0.0 for p in mod.params] + [0.0])
+        v = np.zeros(8)
+        v[:len(mod.nodes)] = [vb.get(x, 0.0) for x in mod.nodes]
+        out = np.zeros(128)
+        n = lib().oracle_va_opvars(mid, P.ctypes.data_as(pd), v.ctypes.data_as(pd), 300.15, 1e-12, out.ctypes.data_as(pd))
+        assert n == len(mod.var_desc) and n > 0
+        for k in range(n):
+            nm = lib().oracle_va_opvar_name(mid, k).decode()
+            assert out[k] == pytest.approx(it.opvars[nm], rel=1e-12, abs=1e-300), (name, nm)
+    # semantic check on the square-law model: saturation, IDS = KP/2 * W/L * Vov^2 * (1 + lambda*Vds)
+    _, mod = find_module("va_mos1")
+    it = Interp(mod, {"KP": 2e-4, "W": 2e-6, "L": 1e-6, "VTO": 0.7, "LAMBDA": 0.0})
+    it.evaluate({"d": 2.0, "g": 1.7})
+    assert it.opvars["REGION"] == 2 and it.opvars["VOV"] == pytest.approx(1.0) and it.opvars["IDS"] == pytest.approx(0.5 * 2e-4 * 2.0 * 1.0)
