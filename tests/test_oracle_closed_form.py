@@ -195,3 +195,40 @@ def test_singular_circuit_reports_error():
     c.C("C", "a", 0, 1e-9)  # no DC path: singular G
     rc, x, _ = Oracle(c).dc(dc_opts(n_restarts=2, maxiters=5))
     assert rc != 0
+
+
+def test_remaining_basic_jl_netlist_cases_solve_to_their_closed_forms():
+    """test/basic.jl:686-737 on the oracle: `device == param` (a resistor named like its parameter inside a subcircuit,
+    with the top-level x1 overridden), the semiconductor resistor (rsh·l/w = 1 kΩ) next to a parameterised one,
+    `.model` case-insensitivity (:597-607) and the `.option` line (:640-649)."""
+    from cedarsim_jl_amd import parse_spice
+    c = parse_spice("""* device == param
+.param x1=1
+.subckt myres p n
+    .param rload=1k
+    rload p n 'rload*x1'
+.ends
+i1 vcc 0 DC -1
+x1 vcc 0 myres
+""").build(x1=2.0)
+    rc, x, _ = Oracle(c).dc(dc_opts(abstol=1e-14))
+    assert rc == 0 and x[c._n("vcc") - 1] == pytest.approx(2000.0, rel=1e-12)       # sol[sys.x1.rload.V] with x1 = 2
+    c = parse_spice("""* semiconductor resistor
+.model myres r rsh=500
+.param res=1k
+v1 vcc 0 1
+R1 vcc 0 myres w=1m l=2m
+R2 vcc 0 res
+""").build()
+    rc, x, _ = Oracle(c).dc(dc_opts(abstol=1e-14))
+    assert rc == 0 and x[c.mna_index("i", "v1")] == pytest.approx(-2e-3, rel=1e-12)   # r1.I = r2.I = 1 mA
+    assert c.dev_par[c.dev_names.index("r1")][0] == pytest.approx(1000.0)
+    c = parse_spice("* .option\n.option temp=10 filemode=ascii noinit\n").build()
+    assert c.temp == 10.0 and c.dev_names == []
+    c = parse_spice("""* .model case sensitivity
+.MODEL MyRes R RSH=500
+V1 vcc 0 1
+r1 VCC 0 myres W=1m L=2m
+""").build()
+    rc, x, _ = Oracle(c).dc(dc_opts(abstol=1e-14))
+    assert rc == 0 and x[c.mna_index("i", "v1")] == pytest.approx(-1e-3, rel=1e-12)
