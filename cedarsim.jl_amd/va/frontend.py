@@ -302,7 +302,8 @@ class Module:
         self.var_desc = {}    # observable variables: name -> text of the (* desc = "..." *) attribute on their declaration
         self.functions = {}
         self.branches = {}    # name -> (a, b|None)
-        self.analog = []      # analog statements in order
+        self.analog = []      # analog statements in order (`analog initial` blocks first)
+        self.n_initial = 0
 
     @property
     def vbranches(self):
@@ -744,7 +745,12 @@ class Parser:
                     self.eat("endfunction")
                     m.functions[f.name] = f
                 else:
-                    m.analog.append(self.statement())
+                    if self.peek()[0] == "id" and self.peek()[1] == "initial":   # `analog initial`: runs before the analog block
+                        self.eat()
+                        m.analog.insert(m.n_initial, ("event", self.statement()))
+                        m.n_initial += 1
+                    else:
+                        m.analog.append(self.statement())
             else:
                 raise VAError("line %d: unexpected %r in module %s" % (line, v, m.name))
         return m

@@ -278,3 +278,13 @@ def test_operating_point_observables_match_interpreter():
     it = Interp(mod, {"KP": 2e-4, "W": 2e-6, "L": 1e-6, "VTO": 0.7, "LAMBDA": 0.0})
     it.evaluate({"d": 2.0, "g": 1.7})
     assert it.opvars["REGION"] == 2 and it.opvars["VOV"] == pytest.approx(1.0) and it.opvars["IDS"] == pytest.approx(0.5 * 2e-4 * 2.0 * 1.0)
+
+
+def test_analog_initial_blocks_run_first():
+    m = parse_va("""module t(a,b); electrical a,b; parameter real R=2.0; real g, k;
+analog begin I(a,b) <+ k*g*V(a,b); end
+analog initial begin g = 1.0/R; end
+analog initial k = 3.0;
+endmodule""")[0]
+    I, Q, G, C = Interp(m).evaluate({"a": 3.0})
+    assert I[0] == pytest.approx(4.5) and G[0][0] == pytest.approx(1.5)
