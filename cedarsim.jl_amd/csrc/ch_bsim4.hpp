@@ -298,11 +298,12 @@ inline int b4_pack(const double* mp, const double* ip, double temp_c, double* ou
 // fp64 division and square root dominate the instruction count of a compact model; the IEEE
 // sequences hipcc emits cost ~11 / ~15 VALU instructions.  frcp/fsqrt use the hardware seeds
 // (v_rcp_f64, v_rsq_f64) plus Newton steps: <= 1-2 ulp, which is far inside the 1e-10 parity bar.
+// v_rcp_f64 is good to 4.6e-8 relative on gfx950 (scripts/rcp_accuracy.hip); one cubically convergent correction
+// r·(1 + e + e²), e = 1 − x·r, brings it to the rounding limit with three FMAs
 CH_D double frcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);
+  return fma(r, fma(e, e, e), r);
 }
 CH_D double fsqrt(double x) {  // x > 0
   double y = __builtin_amdgcn_rsq(x);
