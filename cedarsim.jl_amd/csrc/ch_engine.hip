@@ -9,6 +9,7 @@
 // accept/reject, next step and next order — the job IDA does in the reference (src/sweeps.jl:456).
 // There is NO CPU fallback: without a HIP device ch_create fails.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -241,7 +242,8 @@ struct ch_circuit {
   std::vector<double> sp_rate_v; std::vector<int> sp_status_v;  // per sample: last Newton rate, status of the last solve
   double sp_rate = 1.0;
   // stats
-  double device_ms = 0; long n_launch = 0, n_timed = 0;  // device_ms sums the sampled launches only
+  double device_ms = 0; long n_launch = 0, n_timed = 0;
+  long time_every = std::getenv("CEDARHIP_TIME_EVERY") ? std::max(1L, std::atol(std::getenv("CEDARHIP_TIME_EVERY"))) : 8;  // device_ms sums the sampled launches only
 
   std::string& err() { return ctx->err; }
   void set_err(const std::string& s) { ctx->err = s; }
@@ -762,19 +764,23 @@ struct ch_circuit {
     if (path == 2) return run_sparse(a, host_active, out);
     hipStream_t st = ctx->stream;
     const int nblk = A.n_comp * S;
-    // kernel duration is sampled with HIP events on 1 launch in 8 (the events cost host time on every step)
-    const bool timed = (n_launch & 7) == 0;
-    if (timed) HIPCHK(hipEventRecord(ev0, st));
+    // kernel duration from the dispatch's own start/stop events on one launch in CEDARHIP_TIME_EVERY (default 8; timing every
+    // launch costs ~5 us of host time per step)
+    // sampled pseudo-randomly (a fixed stride aliases with the accept/reject rhythm of the stepper and biased the mean by 9 %)
+    const bool timed = time_every <= 1 || ((uint64_t)(n_launch + 1) * 0x9E3779B97F4A7C15ull >> 33) % (uint64_t)time_every == 0;
+    // timed launches carry their start/stop events in the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the
+    // kernel's own begin-to-end, the quantity rocprofv3 --kernel-trace reports
+    hipEvent_t e0 = timed ? ev0 : nullptr, e1 = timed ? ev1 : nullptr;
+    const dim3 g(nblk), b(block_threads);
     if (A.wide) {
-      if (lu_variant == 16) hipLaunchKernelGGL((newton_block_kernel<16, true>), dim3(nblk), dim3(block_threads), lds_bytes, st, a);
-      else hipLaunchKernelGGL((newton_block_kernel<0, true>), dim3(nblk), dim3(block_threads), lds_bytes, st, a);
+      if (lu_variant == 16) hipExtLaunchKernelGGL((newton_block_kernel<16, true>), g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
+      else hipExtLaunchKernelGGL((newton_block_kernel<0, true>), g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
     }
-    else if (lu_variant == 8) hipLaunchKernelGGL(newton_block_kernel<8>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
-    else if (lu_variant == 12) hipLaunchKernelGGL(newton_block_kernel<12>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
-    else if (lu_variant == 16) hipLaunchKernelGGL(newton_block_kernel<16>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
-    else if (lu_variant == 32) hipLaunchKernelGGL(newton_block_kernel<32>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
-    else hipLaunchKernelGGL(newton_block_kernel<0>, dim3(nblk), dim3(block_threads), lds_bytes, st, a);
-    if (timed) HIPCHK(hipEventRecord(ev1, st));
+    else if (lu_variant == 8) hipExtLaunchKernelGGL(newton_block_kernel<8>, g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
+    else if (lu_variant == 12) hipExtLaunchKernelGGL(newton_block_kernel<12>, g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
+    else if (lu_variant == 16) hipExtLaunchKernelGGL(newton_block_kernel<16>, g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
+    else if (lu_variant == 32) hipExtLaunchKernelGGL(newton_block_kernel<32>, g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
+    else hipExtLaunchKernelGGL(newton_block_kernel<0>, g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
     if (!host_reduce) hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 9 * 256 * sizeof(double), st, a);
     // the host thread has nothing else to do: poll for completion instead of sleeping on an interrupt.
     // (Watching the block records in mapped memory for a per-launch sequence number instead of the stream signal was
