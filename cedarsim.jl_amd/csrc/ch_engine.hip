@@ -243,6 +243,8 @@ struct ch_circuit {
   double sp_rate = 1.0;
   // stats
   double device_ms = 0; long n_launch = 0, n_timed = 0;
+  double prof_launch = 0, prof_wait = 0, prof_reduce = 0;  // host seconds inside run_newton (CEDARHIP_HOST_PROFILE)
+  bool host_profile = std::getenv("CEDARHIP_HOST_PROFILE") != nullptr;
   long time_every = std::getenv("CEDARHIP_TIME_EVERY") ? std::max(1L, std::atol(std::getenv("CEDARHIP_TIME_EVERY"))) : 8;  // device_ms sums the sampled launches only
 
   std::string& err() { return ctx->err; }
@@ -768,6 +770,7 @@ struct ch_circuit {
     // launch costs ~5 us of host time per step)
     // sampled pseudo-randomly (a fixed stride aliases with the accept/reject rhythm of the stepper and biased the mean by 9 %)
     const bool timed = time_every <= 1 || ((uint64_t)(n_launch + 1) * 0x9E3779B97F4A7C15ull >> 33) % (uint64_t)time_every == 0;
+    const auto tp0 = host_profile ? hclock::now() : hclock::time_point();
     // timed launches carry their start/stop events in the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the
     // kernel's own begin-to-end, the quantity rocprofv3 --kernel-trace reports
     hipEvent_t e0 = timed ? ev0 : nullptr, e1 = timed ? ev1 : nullptr;
@@ -782,6 +785,7 @@ struct ch_circuit {
     else if (lu_variant == 32) hipExtLaunchKernelGGL(newton_block_kernel<32>, g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
     else hipExtLaunchKernelGGL(newton_block_kernel<0>, g, b, (uint32_t)lds_bytes, st, e0, e1, 0, a);
     if (!host_reduce) hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 9 * 256 * sizeof(double), st, a);
+    const auto tp1 = host_profile ? hclock::now() : hclock::time_point();
     // the host thread has nothing else to do: poll for completion instead of sleeping on an interrupt.
     // (Watching the block records in mapped memory for a per-launch sequence number instead of the stream signal was
     // tried: the system-scope release each block then needs costs ~28 us per launch; profiles/r01_notes.md.)
@@ -792,6 +796,7 @@ struct ch_circuit {
       if (q != hipSuccess) { set_err(std::string("newton kernel: ") + hipGetErrorString(q)); return CH_ERR_DEVICE; }
     }
     HIPCHK(hipGetLastError());
+    const auto tp2 = host_profile ? hclock::now() : hclock::time_point();
     if (timed) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); device_ms += ms; n_timed += 1; }
     n_launch += 1;
     if (!host_reduce) out = *h_sum;
@@ -813,6 +818,11 @@ struct ch_circuit {
         if (nd > 0) { r.errk = std::max(r.errk, a.ck * std::sqrt(e2[0] / nd)); r.errkm1 = std::max(r.errkm1, a.ckm1 * std::sqrt(e2[1] / nd)); r.errkp1 = std::max(r.errkp1, a.ckp1 * std::sqrt(e2[2] / nd)); }
       }
       out = r;
+    }
+    if (host_profile) {
+      const auto tp3 = hclock::now();
+      prof_launch += std::chrono::duration<double>(tp1 - tp0).count(); prof_wait += std::chrono::duration<double>(tp2 - tp1).count();
+      prof_reduce += std::chrono::duration<double>(tp3 - tp2).count();
     }
     return CH_OK;
   }
@@ -1095,6 +1105,7 @@ struct ch_circuit {
 #endif
     R.status = status;
     R.stats.wall_seconds = std::chrono::duration<double>(hclock::now() - tstart).count();
+    if (host_profile) { std::fprintf(stderr, "[host profile] wall %.3f ms; in run_newton: launch %.3f ms, wait %.3f ms, events+reduce %.3f ms; launches %ld\n", 1e3 * R.stats.wall_seconds, 1e3 * prof_launch, 1e3 * prof_wait, 1e3 * prof_reduce, n_launch); prof_launch = prof_wait = prof_reduce = 0; }
     R.stats.device_seconds = n_timed > 0 ? device_ms * 1e-3 * (double)n_launch / (double)n_timed : 0.0;  // scaled from the sampled launches
     R.stats.n_kernel_launches = n_launch;
     if (status != CH_OK && err().empty()) set_err(status == CH_ERR_DTMIN ? "step size underflow (DtLessThanMin)" : "transient did not reach t1");
