@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from cedarsim_jl_amd import (PULSE, SIN, Circuit, CircuitSweep, ProductSweep, dc, dc_opts, frange, parse_spice,
+from cedarsim_jl_amd import (PULSE, PWL, SIN, Circuit, CircuitSweep, ProductSweep, dc, dc_opts, frange, parse_spice,
                              parse_spice_file, tran, tran_opts)
 from cedarsim_jl_amd import bsim4_params as B4
 from cedarsim_jl_amd.workloads import (DFF_CHECK_Q, DFF_CHECK_TIMES, dff_array, dff_chain, gf180_resolver, inverter, rc_ladder)
@@ -540,3 +540,89 @@ def test_large_batch_uses_the_device_side_reduction(E):
     rc2, t2, v2, _, st2 = e2.tran(0.0, 7e-7, opts())
     assert rc2 == 0 and st2["naccept"] == st["naccept"] and st2["nreject"] == st["nreject"]
     assert np.abs(v2[0] - v[0][:, :2]).max() < 1e-9
+
+
+def _random_circuit(rng, n_nodes, with_mos):
+    """Connected random network: a resistive spanning tree to ground keeps every node's DC value defined; on top of it
+    random R, C, L, I, grounded and floating V sources (incl. 0 V ammeters), VCVS / VCCS and, optionally, MOSFETs."""
+    from cedarsim_jl_amd.workloads import gf180_models
+    c = Circuit(gmin=1e-12)
+    names = ["n%d" % i for i in range(1, n_nodes + 1)]
+    mi = {}
+    if with_mos:
+        m = gf180_models()
+        mi = {"n": c.add_model(*m["nfet_06v0"]), "p": c.add_model(*m["pfet_06v0"])}
+    k = 0
+
+    def nm(p):
+        nonlocal k
+        k += 1
+        return "%s%d" % (p, k)
+
+    def pick():
+        return names[rng.integers(n_nodes)] if rng.random() > 0.15 else 0
+
+    for i, n in enumerate(names):   # spanning tree
+        other = 0 if i == 0 else names[rng.integers(i)]
+        c.R(nm("r"), n, other, float(10 ** rng.uniform(2, 5)))
+    v0 = float(rng.uniform(1, 5))
+    c.V(nm("v"), names[0], 0, dc=v0, tran=PWL([0.0, v0, 2e-7, 0.4 * v0, 5e-7, 0.4 * v0, 6e-7, v0, 1.0, v0]))
+    for _ in range(int(1.5 * n_nodes)):
+        a, b = pick(), pick()
+        if a == b:
+            continue
+        t = rng.random()
+        if t < 0.30:
+            c.R(nm("r"), a, b, float(10 ** rng.uniform(2, 5)), m=float(rng.integers(1, 4)))
+        elif t < 0.45:
+            c.C(nm("c"), a, b, float(10 ** rng.uniform(-13, -10)))
+        elif t < 0.52:
+            c.I(nm("i"), a, b, dc=float(rng.uniform(-1e-3, 1e-3)))
+        elif t < 0.60:
+            mid = c.net(nm("m"))      # inductor in series with a resistor: no V/L loops
+            c.L(nm("l"), a, mid, float(10 ** rng.uniform(-7, -5)))
+            c.R(nm("r"), mid, b, float(10 ** rng.uniform(1, 3)))
+        elif t < 0.70:
+            mid = c.net(nm("m"))      # floating source (sometimes a 0 V ammeter) in series with a resistor
+            c.V(nm("v"), a, mid, dc=0.0 if rng.random() < 0.5 else float(rng.uniform(-1, 1)))
+            c.R(nm("r"), mid, b, float(10 ** rng.uniform(2, 4)))
+        elif t < 0.78:
+            c.G(nm("g"), a, b, pick(), pick(), gain=float(rng.uniform(-1e-4, 1e-4)))
+        elif t < 0.84:
+            mid = c.net(nm("m"))
+            c.E(nm("e"), mid, 0, pick(), pick(), gain=float(rng.uniform(-0.5, 0.5)))
+            c.R(nm("r"), mid, a, float(10 ** rng.uniform(3, 5)))
+        elif with_mos:
+            typ = "n" if rng.random() < 0.5 else "p"
+            c.M(nm("m"), a, pick(), b, 0 if typ == "n" else names[0], mi[typ], float(rng.uniform(0.4e-6, 2e-6)), 6e-7)
+    return c
+
+
+def test_random_circuits_dc_and_residual_parity_with_oracle(E, O):
+    """Differential fuzz of the structural analysis (known nodes, aliases, components, classes) and of the assembly: 24
+    random networks, DC operating point on the GPU against the oracle (rtol 1e-6), plus the engine's own solution
+    plugged into the ORACLE's residual (KCL of the full unreduced MNA system must vanish)."""
+    rng = np.random.default_rng(20251004)
+    worst = 0.0
+    for trial in range(24):
+        c = _random_circuit(rng, int(rng.integers(3, 14)), with_mos=trial % 3 == 0)
+        o = O(c)
+        rc_o, x_o, _ = o.dc(dc_opts(abstol=1e-12))
+        rc, x, status, st = E(c).dc(dc_opts(abstol=1e-12))
+        assert rc_o == 0 and rc == 0, (trial, rc_o, rc)
+        xe = x[0].copy()
+        known = ~np.isnan(xe)
+        assert np.allclose(xe[known], x_o[known], rtol=1e-6, atol=1e-9), (trial, np.abs(xe[known] - x_o[known]).max())
+        xe[~known] = x_o[~known]      # eliminated branch currents: take the oracle's, then check KCL with the engine's voltages
+        F, Q, J = o.eval(xe, 0.0, 0.0, 0)
+        worst = max(worst, float(np.abs(F).max()))
+        assert np.abs(F).max() < 1e-7, (trial, np.abs(F).max())
+        if trial % 3 == 1:   # transient through the PWL corners of the supply: every node against the oracle
+            c.observe_all_nodes()
+            sv = np.array([1e-7, 2e-7, 3.5e-7, 5.5e-7, 6e-7, 1e-6])
+            opts = lambda: tran_opts(abstol=1e-9, reltol=1e-6, saveat=sv, dc=dc_opts(abstol=1e-12, tran_mode=1))  # noqa: E731
+            rce, te, ve, _, _ = E(c).tran(0.0, 1e-6, opts())
+            rco, to, vo, _, _ = O(c).tran(0.0, 1e-6, opts())
+            vo = vo if vo.ndim == 2 else vo[:, :, 0]
+            assert rce == 0 and rco == 0, (trial, rce, rco)
+            assert np.abs(ve[:, :, 0] - vo).max() < 1e-4 * max(1.0, np.abs(vo).max()), (trial, np.abs(ve[:, :, 0] - vo).max())
