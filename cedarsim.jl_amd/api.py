@@ -118,9 +118,21 @@ class Solution:
         return path
 
     def __call__(self, t, idxs=None):
-        """Interpolated observables (linear between saved points; pass `saveat` for exact times)."""
+        """`sol(t, idxs=…)`: observables between saved points by shape-preserving cubic (PCHIP) interpolation of the accepted
+        steps — third order where the waveform is smooth, no overshoot at the corners the stepper landed on.  The engine's own
+        dense output (the BDF polynomial, evaluated on the device) is what `saveat=` returns; use that for exact parity."""
         names = idxs if isinstance(idxs, (list, tuple)) else [idxs]
-        out = [np.interp(t, self.t, self[n]) for n in names]
+        tt = np.asarray(self.t, float)
+        uniq = np.concatenate(([True], np.diff(tt) > 0)) if len(tt) > 1 else np.ones(len(tt), bool)   # restart steps repeat a time
+
+        def interp(y):
+            y = np.asarray(y, float)
+            if uniq.sum() < 3:
+                return np.interp(t, tt, y)
+            from scipy.interpolate import PchipInterpolator
+            return PchipInterpolator(tt[uniq], y[uniq], extrapolate=False)(np.clip(t, tt[0], tt[-1]))
+        out = [interp(self[n]) for n in names]
+        out = [float(o) if np.ndim(o) == 0 else o for o in out]
         return out if isinstance(idxs, (list, tuple)) else out[0]
 
 

@@ -153,3 +153,18 @@ resistor1 (a b) resistor r=1k
     assert set(m) == {"nmos_x", "pmos_x"}
     assert m["nmos_x"][0] == "bsimcmg" and m["nmos_x"][1] == {"type": "n", "level": 110.0, "bulkmod": 1.0, "eot": 1e-9, "phig": 4.3, "l": 2.1e-8}
     assert m["pmos_x"][1] == {"type": "p", "phig": 4.8}
+
+
+def test_solution_call_interpolates_with_pchip():
+    import numpy as np
+    from cedarsim_jl_amd import Circuit
+    from cedarsim_jl_amd.api import Solution
+    c = Circuit()
+    c.V("v1", "a", 0, dc=1.0)
+    c.R("r1", "a", 0, 1.0)
+    t = np.sort(np.concatenate(([0.0, 1.0], np.random.default_rng(0).uniform(0, 1, 60))))
+    t = np.insert(t, 20, t[20])                          # a repeated time, as after a break-point restart
+    sol = Solution(c, t, {("v", c._n("a")): np.sin(6 * t)}, None, 0, {})
+    tq = np.linspace(0.01, 0.99, 200)
+    assert np.abs(sol(tq, idxs="node_a") - np.sin(6 * tq)).max() < 2e-3      # linear interpolation would be ~1e-2 here
+    assert isinstance(sol(0.5, idxs="node_a"), float) and len(sol(0.5, idxs=["node_a"])) == 1
