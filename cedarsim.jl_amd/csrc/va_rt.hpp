@@ -137,6 +137,9 @@ template <int N, class S> VA_HD VD<N, S> v_pow(const VD<N, S>& a, const VD<N, S>
 }
 template <int N, class S> VA_HD VD<N, S> v_pow(double a, const VD<N, S>& b) { return v_pow(VD<N, S>(a), b); }
 
+// array index: offset by the lower bound; out-of-range indices are clamped (the interpreter raises instead)
+VA_HD int clamp_index(int i, int lo, int hi) { return (i < lo ? lo : (i > hi ? hi : i)) - lo; }
+
 // VA real → integer: round half away from zero (LRM 4.2.1.1, src/va_env.jl:107)
 VA_HD int to_int(double x) { return (int)(x >= 0.0 ? ::floor(x + 0.5) : -::floor(-x + 0.5)); }
 VA_HD int to_int(int x) { return x; }

@@ -63,7 +63,7 @@ def _unjson(x):
 
 def module_to_json(m):
     return {"name": m.name, "ports": m.ports, "internal": m.internal, "params": _jsonable(m.params), "aliases": m.aliases,
-            "vars": m.vars, "var_desc": m.var_desc, "branches": _jsonable(m.branches), "analog": _jsonable(m.analog),
+            "vars": m.vars, "var_desc": m.var_desc, "arrays": {k: list(v) for k, v in m.arrays.items()}, "branches": _jsonable(m.branches), "analog": _jsonable(m.analog),
             "functions": {k: {"rtype": f.rtype, "args": _jsonable(f.args), "vars": f.vars, "body": _jsonable(f.body)} for k, f in m.functions.items()}}
 
 
@@ -74,6 +74,7 @@ def module_from_json(j):
     m.params = [tuple(p) for p in _unjson(j["params"])]
     m.aliases, m.vars = dict(j["aliases"]), dict(j["vars"])
     m.var_desc = dict(j.get("var_desc", {}))
+    m.arrays = {k: tuple(v) for k, v in j.get("arrays", {}).items()}
     m.branches = {k: tuple(v) for k, v in _unjson(j["branches"]).items()}
     m.analog = _unjson(j["analog"])
     for k, fj in j["functions"].items():

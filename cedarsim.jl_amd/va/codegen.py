@@ -80,7 +80,7 @@ class ModuleGen:
         k = e[0]
         if k in ("num", "str"):
             return False
-        if k == "id":
+        if k in ("id", "index"):
             return e[1] in self.dual
         if k == "un":
             return self._is_dual(e[2])
@@ -109,6 +109,9 @@ class ModuleGen:
                 if not n:
                     continue
                 if n[0] == "assign" and n[1] not in self.dual and self.all_vars.get(n[1]) == "real" and self._is_dual(n[2]):
+                    self.dual.add(n[1])
+                    changed = True
+                if n[0] == "assign_idx" and n[1] not in self.dual and self.all_vars.get(n[1]) == "real" and self._is_dual(n[3]):
                     self.dual.add(n[1])
                     changed = True
                 if n[0] == "call" and n[1] in self.m.functions:
@@ -162,6 +165,12 @@ class ModuleGen:
             raise VAError("undefined identifier '%s' in module %s" % (name, self.m.name))
         if k == "str":
             raise VAError("string in an arithmetic expression")
+        if k == "index":
+            name = e[1]
+            if name not in ctx["vars"] or name not in self.m.arrays:
+                raise VAError("'%s' is not an array variable" % name)
+            ic, it = self.expr(e[2], ctx)
+            return "v_%s[va::clamp_index(%s, %d, %d)]" % (name, self.cast(ic, it, "int", S), self.m.arrays[name][0], self.m.arrays[name][1]), ctx["vars"][name]
         if k == "un":
             c, t = self.expr(e[2], ctx)
             if e[1] == "-":
@@ -378,6 +387,14 @@ class ModuleGen:
         k = st[0]
         pad = "  " * ind
         S = ctx["S"]
+        if k == "assign_idx":
+            name = st[1]
+            if name not in ctx["vars"] or name not in self.m.arrays:
+                raise VAError("'%s' is not an array variable" % name)
+            ic, it = self.expr(st[2], ctx)
+            c, t = self.expr(st[3], ctx)
+            lo, hi = self.m.arrays[name]
+            return ["%sv_%s[va::clamp_index(%s, %d, %d)] = %s;" % (pad, name, self.cast(ic, it, "int", S), lo, hi, self.cast(c, t, ctx["vars"][name], S))]
         if k == "assign":
             name = st[1]
             if name not in ctx["vars"]:
@@ -451,7 +468,7 @@ class ModuleGen:
                 for nm, ty in st[2].items():
                     t = "int" if ty == "integer" else ("dual" if (ctx.get("infunc") or nm in self.dual) else "real")
                     ctx["vars"][nm] = t
-                    out.append("%s  %s v_%s = 0;" % (pad, {"int": "int", "real": "double", "dual": S}[t], nm))
+                    out.append("%s  %s v_%s%s;" % (pad, {"int": "int", "real": "double", "dual": S}[t], nm, self._decl_suffix(nm)))
             for s in st[3]:
                 out += self.stmt(s, ctx, ind + 1)
             return out + ["%s}" % pad]
@@ -498,6 +515,12 @@ class ModuleGen:
             return []
         raise VAError("cannot generate statement %r" % (st,))
 
+    def _decl_suffix(self, name):
+        if name in self.m.arrays:
+            lo, hi = self.m.arrays[name]
+            return "[%d] = {}" % (hi - lo + 1)
+        return " = 0"
+
     def q_mask(self):
         """Bit k set: node k receives a ddt() contribution somewhere in the analog block."""
         mask = 0
@@ -529,7 +552,7 @@ class ModuleGen:
             t = "int" if ty == "integer" else "dual"
             vars_[nm] = t
             if nm not in argn:
-                out.append("  %s v_%s = 0;" % ("int" if t == "int" else "S", nm))
+                out.append("  %s v_%s%s;" % ("int" if t == "int" else "S", nm, self._decl_suffix(nm)))
         out.append("  (void)env;")
         ctx = {"vars": vars_, "S": "S", "infunc": True}
         out += self.stmt(f.body, ctx, 1)
@@ -566,7 +589,7 @@ class ModuleGen:
             vars_[nm] = "int" if ty == "integer" else ("dual" if nm in self.dual else "real")
 
         def var_decls(scalar):
-            return ["  %s v_%s = 0;" % ({"int": "int", "real": "double", "dual": scalar}[t], nm) for nm, t in vars_.items()]
+            return ["  %s v_%s%s;" % ({"int": "int", "real": "double", "dual": scalar}[t], nm, self._decl_suffix(nm)) for nm, t in vars_.items()]
         out += param_decls + var_decls("R")
         out.append("  (void)env; (void)V; (void)P;")
         for key in m.vbranches:   # voltage branches: KCL rows get ±x_br, the branch row starts as V(a) − V(b)

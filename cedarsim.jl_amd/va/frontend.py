@@ -302,6 +302,7 @@ class Module:
         self.var_desc = {}    # observable variables: name -> text of the (* desc = "..." *) attribute on their declaration
         self.functions = {}
         self.branches = {}    # name -> (a, b|None)
+        self.arrays = {}      # array variables: name -> (lo, hi)
         self.analog = []      # analog statements in order (`analog initial` blocks first)
         self.n_initial = 0
 
@@ -355,6 +356,7 @@ _BINPREC = [("||",), ("&&",), ("|",), ("^",), ("&",), ("==", "!="), ("<", "<=", 
 class Parser:
     def __init__(self, toks):
         self.t, self.i = toks, 0
+        self.arrays = {}   # name -> (lo, hi) of every array variable declared so far (module, block or function level)
 
     # -- token helpers --
     def peek(self, k=0):
@@ -460,6 +462,11 @@ class Parser:
                         break
                 self.eat(")")
                 return ("call", name, args)
+            if k == "id" and self.at("["):
+                self.eat()
+                ix = self.expr()
+                self.eat("]")
+                return ("index", name, ix)
             return ("call", name, []) if k == "sys" else ("id", name)
         raise VAError("line %d: unexpected %r in expression" % (line, v))
 
@@ -587,17 +594,42 @@ class Parser:
 
     def assignment(self):
         name = self.ident()
+        if self.at("["):
+            self.eat()
+            ix = self.expr()
+            self.eat("]")
+            self.eat("=")
+            return ("assign_idx", name, ix, self.expr())
         self.eat("=")
         return ("assign", name, self.expr())
 
+    def _const_int(self):
+        e = self.expr()
+        sign = 1
+        while e[0] == "un" and e[1] == "-":
+            sign, e = -sign, e[2]
+        if e[0] != "num" or not e[2]:
+            raise VAError("line %d: array bounds must be integer literals" % self.peek()[2])
+        return sign * e[1]
+
     def idlist(self):
-        names = [self.ident()]
-        if self.at("="):   # `real x = 1.0` initialisers are not part of the subset
-            raise VAError("line %d: variable initialisers are not supported" % self.peek()[2])
-        while self.at(","):
-            self.eat()
-            names.append(self.ident())
-        return names
+        names = []
+        while True:
+            nm = self.ident()
+            if self.at("["):   # array variable: real x[lo:hi]
+                self.eat()
+                lo = self._const_int()
+                self.eat(":")
+                hi = self._const_int()
+                self.eat("]")
+                self.arrays[nm] = (min(lo, hi), max(lo, hi))
+            if self.at("="):   # `real x = 1.0` initialisers are not part of the subset
+                raise VAError("line %d: variable initialisers are not supported" % self.peek()[2])
+            names.append(nm)
+            if self.at(","):
+                self.eat()
+                continue
+            return names
 
     # -- module level --
     def source(self):
@@ -636,6 +668,7 @@ class Parser:
     def module(self):
         self.eat()
         m = Module(self.ident())
+        m.arrays = self.arrays = {}
         if self.at("("):
             self.eat()
             if not self.at(")"):

@@ -281,6 +281,11 @@ class _Frame:
     def __init__(self, types):
         self.types, self.vals = dict(types), {}
 
+    def init(self, arrays):
+        for nm, ty in self.types.items():
+            z = 0 if ty == "integer" else 0.0
+            self.vals[nm] = [z] * (arrays[nm][1] - arrays[nm][0] + 1) if nm in arrays else z
+
 
 class Interp:
     """One module instance: parameters resolved, then `evaluate(V)` any number of times."""
@@ -372,8 +377,7 @@ class Interp:
         self.contribs = []   # (access, nodes, kind) executed, for the structure probe
         self.noise = []
         fr = _Frame(m.vars)
-        for nm, ty in m.vars.items():
-            fr.vals[nm] = 0 if ty == "integer" else 0.0
+        fr.init(m.arrays)
         # voltage branches: unknown branch current x_br; KCL rows get ±x_br, the branch row starts as V(a) − V(b)
         for key in m.vbranches:
             kb = self.node_ix[m.branch_node(key)]
@@ -446,6 +450,13 @@ class Interp:
             return self.lookup(e[1], fr)
         if k == "str":
             return e[1]
+        if k == "index":
+            arr = self.lookup(e[1], fr)
+            lo, hi = self.m.arrays[e[1]]
+            i = va_round(self.ev(e[2], fr))
+            if not lo <= i <= hi:
+                raise VAError("index %d outside %s[%d:%d]" % (i, e[1], lo, hi))
+            return arr[i - lo]
         if k == "un":
             x = self.ev(e[2], fr)
             if e[1] == "-":
@@ -554,8 +565,7 @@ class Interp:
         if len(args) != len(f.args):
             raise VAError("function %s expects %d arguments" % (f.name, len(f.args)))
         loc = _Frame(f.vars)
-        for nm, ty in f.vars.items():
-            loc.vals[nm] = 0 if ty == "integer" else 0.0
+        loc.init(self.m.arrays)
         for (nm, kind), a in zip(f.args, args):
             if kind in ("input", "inout"):
                 self.assign(nm, self.ev(a, fr), loc)
@@ -602,7 +612,19 @@ class Interp:
 
     def ex(self, st, fr):
         k = st[0]
-        if k == "assign":
+        if k == "assign_idx":
+            lo, hi = self.m.arrays[st[1]]
+            i = va_round(self.ev(st[2], fr))
+            if not lo <= i <= hi:
+                raise VAError("index %d outside %s[%d:%d]" % (i, st[1], lo, hi))
+            f = fr
+            while f is not None and st[1] not in f.types:
+                f = getattr(f, "parent", None)
+            if f is None:
+                raise VAError("assignment to undeclared array '%s'" % st[1])
+            v = self.ev(st[3], fr)
+            f.vals[st[1]][i - lo] = va_round(v) if f.types[st[1]] == "integer" else v
+        elif k == "assign":
             self.assign(st[1], self.ev(st[2], fr), fr)
         elif k == "contrib":
             acc, nodes = st[1], st[2]
@@ -647,8 +669,7 @@ class Interp:
             if st[2]:
                 inner = _Frame(st[2])
                 inner.parent = fr
-                for nm, ty in st[2].items():
-                    inner.vals[nm] = 0 if ty == "integer" else 0.0
+                inner.init(self.m.arrays)
                 fr = inner
             for s in st[3]:
                 self.ex(s, fr)

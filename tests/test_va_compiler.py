@@ -298,8 +298,8 @@ module cg_torture(a, b, c);
   parameter integer N = 3 from [0:8];
   parameter integer MODE = 2;
   parameter real VT = 0.5;
-  real g, acc, vx, q1, tmp, w;
-  integer i, flags, k;
+  real g, acc, vx, q1, tmp, w, tab[0:3];
+  integer i, flags, k, pick[1:2];
 
   analog function real softplus;
     input x, s; real x, s;
@@ -347,6 +347,10 @@ module cg_torture(a, b, c);
     q1 = 1e-12*( (vx > 0.2) ? pow(vx, 1.5) : ((vx < -0.2) ? -hypot(vx, 0.1) : vx) ) + 1e-13*atan2(V(c), 1.0 + abs(vx));
     I(a, b) <+ g*(acc + w*vx) + ddt(q1);
     I(c, b) <+ 1e-4*(lpos - 0.5*lneg) + 1e-6*(k - 10) + 1e-5*max(min(tmp, 0.3), -0.3);
+    // array variables with computed indices
+    for (i = 0; i <= 3; i = i + 1) tab[i] = tanh((i + 1)*V(c))/(i + 1);
+    pick[1] = MODE % 4; pick[2] = 3 - pick[1];
+    I(c, a) <+ 1e-5*(tab[pick[1]] - tab[pick[2]] + tab[N % 4]);
     I(a, n1) <+ 1e-2*V(a, n1);
     I(n1, c) <+ 1e-2*limexp(V(n1, c)) - 1e-2 + ddt(2e-12*V(n1, c)*V(n1, c));
   end
