@@ -414,16 +414,7 @@ class ModuleGen:
                     return ["%s/* V(%s) <+ 0: node collapse handled at circuit build */" % (pad, ",".join(nodes))]
                 if ctx.get("noise"):
                     return []
-                name, sgn = self.m.find_vbranch(nodes)
-                kb = self.node_ix[name]
-                r, q = self.split_ddt(st[3])
-                out = []
-                for ast, arr in ((r, "I"), (q, "Q")):   # branch row: V(a,b) − Σ expr = 0
-                    if ast is None:
-                        continue
-                    c, t = self.expr(ast, ctx)
-                    out.append("%s{ const %s c_ = %s; %s[%d] %s c_; }" % (pad, S, self.cast(c, t, "dual", S), arr, kb, "-=" if sgn > 0 else "+="))
-                return out
+                return self._branch_contrib(nodes, 1, st[3], ctx, pad)
             if acc not in FLOW_ACCESS:
                 raise VAError("unknown access function %s" % acc)
             rhs = st[3]
@@ -444,6 +435,8 @@ class ModuleGen:
                         (pad, a, b, self.cast(pc, pt, "real", S), self.cast(ec, et, "real", S))]
             if is_noise:
                 return []
+            if self.m.find_vbranch(nodes) is not None:   # current contribution to a voltage / switch branch
+                return self._branch_contrib(nodes, 0, st[3], ctx, pad)
             r, q = self.split_ddt(st[3])
             a = self.node_ix[nodes[0]]
             b = self.node_ix[nodes[1]] if len(nodes) > 1 else None
@@ -515,6 +508,20 @@ class ModuleGen:
             return []
         raise VAError("cannot generate statement %r" % (st,))
 
+    def _branch_contrib(self, nodes, kind, rhs, ctx, pad):
+        """Contribution to a voltage / switch branch: state (0 CURRENT, 1 VOLTAGE) and value as in src/vasim.jl:128-180."""
+        S = ctx["S"]
+        name, sgn = self.m.find_vbranch(nodes)
+        k = [self.m.branch_node(key) for key in self.m.vbranches].index(name)
+        r, q = self.split_ddt(rhs)
+        out = ["%sif (bs%d_ != %d) { bs%d_ = %d; bv%d_ = %s(0.0); bq%d_ = %s(0.0); }" % (pad, k, kind, k, kind, k, S, k, S)]
+        for ast, var in ((r, "bv"), (q, "bq")):
+            if ast is None:
+                continue
+            c, t = self.expr(ast, ctx)
+            out.append("%s%s%d_ %s %s;" % (pad, var, k, "+=" if sgn > 0 else "-=", self.cast(c, t, "dual", S)))
+        return out
+
     def _decl_suffix(self, name):
         if name in self.m.arrays:
             lo, hi = self.m.arrays[name]
@@ -534,8 +541,12 @@ class ModuleGen:
                 nodes = n[2]
                 if len(nodes) == 1 and nodes[0] in self.m.branches:
                     nodes = [x for x in self.m.branches[nodes[0]] if x is not None]
-                for nd in nodes:
-                    mask |= 1 << self.node_ix[nd]
+                vb = self.m.find_vbranch(nodes)
+                if vb is not None:
+                    mask |= 1 << self.node_ix[vb[0]]
+                else:
+                    for nd in nodes:
+                        mask |= 1 << self.node_ix[nd]
         return mask
 
     # ---- top level ----
@@ -592,15 +603,16 @@ class ModuleGen:
             return ["  %s v_%s%s;" % ({"int": "int", "real": "double", "dual": scalar}[t], nm, self._decl_suffix(nm)) for nm, t in vars_.items()]
         out += param_decls + var_decls("R")
         out.append("  (void)env; (void)V; (void)P;")
-        for key in m.vbranches:   # voltage branches: KCL rows get ±x_br, the branch row starts as V(a) − V(b)
-            kb, a = self.node_ix[m.branch_node(key)], self.node_ix[key[0]]
-            out.append("  I[%d] += V[%d]; I[%d] += V[%d];" % (a, kb, kb, a))
-            if len(key) > 1:
-                b = self.node_ix[key[1]]
-                out.append("  I[%d] -= V[%d]; I[%d] -= V[%d];" % (b, kb, kb, b))
+        for k in range(len(m.vbranches)):   # voltage / switch branches: state (CURRENT at the start), value, charge
+            out.append("  int bs%d_ = 0; R bv%d_ = R(0.0), bq%d_ = R(0.0);" % (k, k, k))
         ctx = {"vars": vars_, "S": "R"}
         for st in m.analog:
             out += self.stmt(st, ctx, 1)
+        for k, key in enumerate(m.vbranches):   # KCL rows get ±x_br; branch row: x_br − value (CURRENT) or V(a,b) − value (VOLTAGE)
+            kb, a = self.node_ix[m.branch_node(key)], self.node_ix[key[0]]
+            vab = "V[%d]" % a if len(key) == 1 else "(V[%d] - V[%d])" % (a, self.node_ix[key[1]])
+            out.append("  I[%d] += V[%d];%s" % (a, kb, (" I[%d] -= V[%d];" % (self.node_ix[key[1]], kb)) if len(key) > 1 else ""))
+            out.append("  I[%d] += (bs%d_ == 1 ? %s : V[%d]) - bv%d_; Q[%d] -= bq%d_;" % (kb, k, vab, kb, k, kb, k))
         out.append("}")
         # noise pass: same statements over plain doubles, contributions replaced by noise records
         self.has_noise = any(n and n[0] == "call" and n[1] in ("white_noise", "flicker_noise") for n in _walk(m.analog))

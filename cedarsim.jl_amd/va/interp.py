@@ -378,19 +378,23 @@ class Interp:
         self.noise = []
         fr = _Frame(m.vars)
         fr.init(m.arrays)
-        # voltage branches: unknown branch current x_br; KCL rows get ±x_br, the branch row starts as V(a) − V(b)
-        for key in m.vbranches:
+        # voltage / switch branches (src/vasim.jl:128-180): the branch current x_br is an unknown; the branch carries a state
+        # (CURRENT at the start of every evaluation) and a value; a contribution of the other kind resets the value and
+        # switches the state; at the end the branch row is `x_br − value` (CURRENT) or `V(a,b) − value` (VOLTAGE)
+        self.bstate = {key: ["I", 0.0, None] for key in m.vbranches}
+        for st in m.analog:
+            self.ex(st, fr)
+        for key, (state, value, charge) in self.bstate.items():
             kb = self.node_ix[m.branch_node(key)]
             xb = self.V[m.branch_node(key)]
             a = self.node_ix[key[0]]
             self.Ires[a] = self.Ires[a] + xb
-            self.Ires[kb] = self.Ires[kb] + self.V[key[0]]
             if len(key) > 1:
-                b = self.node_ix[key[1]]
-                self.Ires[b] = self.Ires[b] - xb
-                self.Ires[kb] = self.Ires[kb] - self.V[key[1]]
-        for st in m.analog:
-            self.ex(st, fr)
+                self.Ires[self.node_ix[key[1]]] = self.Ires[self.node_ix[key[1]]] - xb
+            lhs = xb if state == "I" else (self.V[key[0]] - (self.V[key[1]] if len(key) > 1 else 0.0))
+            self.Ires[kb] = self.Ires[kb] + lhs - value
+            if charge is not None:
+                self.Qres[kb] = self.Qres[kb] - charge
         self.structure = list(self.contribs)
         self.opvars = {nm: val(fr.vals[nm]) for nm in m.var_desc if nm in fr.vals}   # (* desc *) observables
 
@@ -610,6 +614,17 @@ class Interp:
             raise VAError("ddt() must appear as an additive (possibly scaled) term of a contribution")
         return self.ev(e, fr), None
 
+    def _branch_contrib(self, nodes, kind, rhs, fr):
+        name, sgn = self.m.find_vbranch(nodes)
+        key = next(k for k in self.m.vbranches if self.m.branch_node(k) == name)
+        rec = self.bstate[key]
+        if rec[0] != kind:
+            rec[0], rec[1], rec[2] = kind, 0.0, None
+        r, q = self.split_ddt(rhs, fr)
+        rec[1] = rec[1] + sgn * r
+        if q is not None:
+            rec[2] = (rec[2] if rec[2] is not None else 0.0) + sgn * q
+
     def ex(self, st, fr):
         k = st[0]
         if k == "assign_idx":
@@ -634,12 +649,7 @@ class Interp:
                 if _is_zero(st[3]):
                     self.contribs.append(("V", tuple(nodes), "collapse"))
                     return
-                name, sgn = self.m.find_vbranch(nodes)
-                kb = self.node_ix[name]
-                r, q = self.split_ddt(st[3], fr)
-                self.Ires[kb] = self.Ires[kb] - sgn * r          # branch row: V(a,b) − Σ expr = 0
-                if q is not None:
-                    self.Qres[kb] = self.Qres[kb] - sgn * q
+                self._branch_contrib(nodes, "V", st[3], fr)
                 self.contribs.append(("V", tuple(nodes), "branch"))
                 return
             if st[3][0] == "call" and st[3][1] in ("white_noise", "flicker_noise"):
@@ -648,6 +658,10 @@ class Interp:
                 vals = [val(self.ev(a, fr)) for a in nargs]
                 self.noise.append({"kind": st[3][1], "nodes": tuple(nodes), "pwr": vals[0], "exp": vals[1] if st[3][1] == "flicker_noise" else 0.0,
                                    "name": args[-1][1] if (args and args[-1][0] == "str") else ""})
+                return
+            if self.m.find_vbranch(nodes) is not None:   # current contribution to a voltage / switch branch
+                self._branch_contrib(nodes, "I", st[3], fr)
+                self.contribs.append(("I", tuple(nodes), "branch"))
                 return
             r, q = self.split_ddt(st[3], fr)
             a = self.node_ix[nodes[0]]

@@ -344,3 +344,14 @@ def test_operating_point_observables_on_the_gpu(ctx):
         for k, v in opn.items():
             assert v == pytest.approx(it.opvars[k], rel=1e-8, abs=1e-30), k
         assert opn["IDS"] > 1e-6                                    # the n-FET conducts at the switching point
+
+
+def test_switch_branch_on_the_gpu(E):
+    for vc, want in ((1.0, 1000.0 / 1001.0), (0.0, 1e-9 * 1000.0 / (1 + 1e-9 * 1000.0))):
+        c = Circuit()
+        c.V("v1", "in", 0, dc=1.0)
+        c.V("vc", "ctl", 0, dc=vc)
+        c.VA("s1", "va_switch", ["in", "out", "ctl"], {})
+        c.R("rl", "out", 0, 1e3)
+        rc, x, status, st = E(c).dc(dc_opts(abstol=1e-15))
+        assert rc == 0 and x[0][c._n("out") - 1] == pytest.approx(want, rel=1e-9)

@@ -127,7 +127,7 @@ def test_generated_code_matches_interpreter_library_models():
     for name, params in (("va_resistor", {"R": 2e3}), ("va_resistor_rev", {}), ("va_nlvcr", {"R": 2.0}), ("va_capacitor", {"C": 3e-12}),
                          ("va_diode", {"IS": 2e-14, "RS": 5.0, "LEVEL": 2}), ("va_diode", {}), ("va_mos1", {"TYPE": -1, "W": 4e-6, "CGSO": 1e-10}),
                          ("va_mos1", {"KP": 2e-4}), ("va_inductor", {"L": 2e-6, "RS": 3.0}), ("va_vcvs", {"VDC": 1.5, "GAIN": -2.0}),
-                         ("va_noisy_resistor", {"KF": 1e-12})):
+                         ("va_noisy_resistor", {"KF": 1e-12}), ("va_switch", {"VTH": 0.3}), ("va_switch", {"VTH": 5.0})):
         _, mod = find_module(name)
         _codegen_vs_interp(name, params, [_random_bias(mod, rng) for _ in range(6)], temp_c=40.0)
 
@@ -392,3 +392,23 @@ def test_generated_cpp_matches_interpreter_on_a_torture_module(tmp_path):
             for got, want in ((st[:4], I), (st[8:12], Q), (st[16:80].reshape(8, 8)[:4, :4], G), (st[80:144].reshape(8, 8)[:4, :4], Cm)):
                 want = np.array(want, float)
                 assert np.allclose(got, want, rtol=1e-11, atol=1e-11 * max(np.abs(want).max(), 1e-300)), (params, vb)
+
+
+def test_switch_branch_state_semantics():
+    """A branch that receives a voltage contribution on one path and a current contribution on the other: the branch state
+    follows the last contribution executed (src/vasim.jl:128-180, 810-822)."""
+    _, mod = find_module("va_switch")
+    assert mod.nodes == ["p", "n", "c", "I(p,n)"]
+    # closed: row x_br: V(p,n) - RON*x_br ; open: x_br - GOFF*V(p,n)
+    I, Q, G, C = Interp(mod, {"RON": 2.0}).evaluate({"p": 1.0, "n": 0.0, "c": 1.0, "I(p,n)": 0.25})
+    assert I == [0.25, -0.25, 0.0, 1.0 - 2.0 * 0.25] and G[3] == [1.0, -1.0, 0.0, -2.0]
+    I, Q, G, C = Interp(mod, {"GOFF": 1e-3}).evaluate({"p": 1.0, "n": 0.0, "c": 0.0, "I(p,n)": 0.25})
+    assert I == [0.25, -0.25, 0.0, 0.25 - 1e-3] and G[3] == [-1e-3, 1e-3, 0.0, 1.0]
+    for vc, want in ((1.0, 1000.0 / 1001.0), (0.0, 1e-9 * 1000.0 / (1 + 1e-9 * 1000.0))):
+        c = Circuit()
+        c.V("v1", "in", 0, dc=1.0)
+        c.V("vc", "ctl", 0, dc=vc)
+        c.VA("s1", "va_switch", ["in", "out", "ctl"], {})
+        c.R("rl", "out", 0, 1e3)
+        rc, x, _ = Oracle(c).dc(dc_opts(abstol=1e-15))
+        assert rc == 0 and x[c._n("out") - 1] == pytest.approx(want, rel=1e-9)
