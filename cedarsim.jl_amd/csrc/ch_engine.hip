@@ -258,6 +258,8 @@ struct ch_circuit {
     if (h_red) (void)hipHostFree(h_red);
     if (h_flag) (void)hipHostFree(h_flag);
     if (h_stage) (void)hipHostFree(h_stage);
+    if (h_act) (void)hipHostFree(h_act);
+    if (h_scale) (void)hipHostFree(h_scale);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
   }
@@ -612,6 +614,7 @@ struct ch_circuit {
     d.ulvl_ptr = pd.ulvl_ptr.p; d.ulvl_rows = pd.ulvl_rows.p; d.lrow_ptr = pd.lrow_ptr.p; d.l_pos = pd.l_pos.p; d.l_k = pd.l_k.p; d.l_upd_ptr = pd.l_upd_ptr.p;
     d.upd_dst = pd.upd_dst.p; d.upd_src = pd.upd_src.p; d.urow_ptr = pd.urow_ptr.p; d.u_pos = pd.u_pos.p; d.u_col = pd.u_col.p;
     d.s = sm; d.xofs = (long)sm * (long)n;
+    d.st_stage = (long)(nd * A.stride()); d.st_nnz = (long)nnz; d.st_lu = (long)std::max(0, P.nnz_lu); d.st_n = (long)n;
     d.stride = A.stride(); d.q_ofs = A.wide ? 8 : 4; d.c_ofs = A.wide ? 64 : 16; d.wide = A.wide ? 1 : 0;
     d.n = A.n_unk; d.nnz = (int)nnz; d.nnz_lu = P.nnz_lu; d.n_lvl = P.valid ? (int)P.lvl_ptr.size() - 1 : 0; d.n_ulvl = P.valid ? (int)P.ulvl_ptr.size() - 1 : 0; d.n_dev = (int)nd;
     // per-sample slices of the work arrays
@@ -651,6 +654,22 @@ struct ch_circuit {
   // One Newton solve per sample (same contract as the fused kernel: reads the history ring, writes the candidate
   // slot).  Samples share the symbolic plan and the pivot order; every phase is queued for all active samples and
   // the host synchronises once per phase, so the number of round trips does not grow with the sample count.
+  // device copies of a sample list / per-sample scales, staged through pinned memory (rewritten only after a stream sync)
+  DevBuf<int> sp_act[3]; DevBuf<double> sp_scale;
+  int* h_act = nullptr; double* h_scale = nullptr; size_t h_act_n = 0;
+  int stage_list(int slot, const std::vector<int>& list) {
+    if (h_act_n < (size_t)S) {
+      if (h_act) (void)hipHostFree(h_act);
+      if (h_scale) (void)hipHostFree(h_scale);
+      HIPCHK(hipHostMalloc((void**)&h_act, 3 * (size_t)S * sizeof(int))); HIPCHK(hipHostMalloc((void**)&h_scale, (size_t)S * sizeof(double)));
+      h_act_n = (size_t)S;
+    }
+    g_arena = &arena;
+    HIPCHK(sp_act[slot].alloc((size_t)S));
+    std::memcpy(h_act + (size_t)slot * S, list.data(), list.size() * sizeof(int));
+    HIPCHK(hipMemcpyAsync(sp_act[slot].p, h_act + (size_t)slot * S, list.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    return CH_OK;
+  }
   int run_sparse(NewtonArgs a, const unsigned char* host_active, Summary& out) {
     hipStream_t st = ctx->stream;
     const int which = a.mode == MODE_DC ? 0 : 1;
@@ -661,7 +680,6 @@ struct ch_circuit {
       HIPCHK(hipMemcpyAsync(d_kv.p, h_stage, (size_t)(a.nk + a.nsrc) * sizeof(double), hipMemcpyHostToDevice, st));
       a.inline_vals = 0;
     }
-    const dim3 b256(256), gn((n + 255) / 256), gd((nd + 63) / 64), ga((std::max(n, nnz) + 255) / 256);
     std::memset(&out, 0, sizeof(out));
     const int maxit = a.mode == MODE_EVAL ? 0 : a.maxit;
     std::vector<int> todo;   // samples taking part in this solve
@@ -670,23 +688,31 @@ struct ch_circuit {
       for (int k = 0; k < A.n_comp && !on; ++k) on = host_active[(size_t)k * S + sm] != 0;
       if (on) todo.push_back(sm);
     }
+    if (todo.empty()) return CH_OK;
     std::vector<int> status(S, 1), iters(S, 0);
     std::vector<double> rate_prev(S, 1.0), rate_new(S, -1.0), dn_prev(S, 0.0), fnorm(S, 0.0), scale(S, 1.0);
-    for (int sm : todo) { rate_prev[sm] = (a.mode == MODE_TRAN && !a.reset_rate) ? sp_rate_v[sm] : 1.0; hipLaunchKernelGGL(sp_predict_kernel, gn, b256, 0, st, a, sparse_dev(which, sm)); }
-    std::vector<int> act = todo;   // samples still iterating
+    for (int sm : todo) rate_prev[sm] = (a.mode == MODE_TRAN && !a.reset_rate) ? sp_rate_v[sm] : 1.0;
+    const dim3 b256(256), b1k(1024);
+    auto grid = [&](int nx, size_t nl) { return dim3((unsigned)nx, (unsigned)nl); };
+    const int gn = (n + 255) / 256, gd = (nd + 63) / 64, ga = (std::max(n, nnz) + 255) / 256;
+    // slot 0: every sample of this solve (predict, commit); slot 1: samples still iterating; slot 2: samples to (re)factor
+    int rc = stage_list(0, todo); if (rc != CH_OK) return rc;
+    hipLaunchKernelGGL(sp_predict_kernel, grid(gn, todo.size()), b256, 0, st, a, sparse_dev(which), (const int*)sp_act[0].p);
+    std::vector<int> act = todo;
+    rc = stage_list(1, act); if (rc != CH_OK) return rc;
     const bool damp = a.mode == MODE_DC && a.dv_max > 0.0 && (!A.mos_hdev.empty() || A.wide);
     for (int it = 0; it <= maxit && !act.empty(); ++it) {
-      for (int sm : act) {
-        const SparseDev d = sparse_dev(which, sm);
-        hipLaunchKernelGGL(sp_eval_kernel, gd, dim3(64), 0, st, a, d);
-        hipLaunchKernelGGL(sp_assemble_kernel, ga, b256, 0, st, a, d);
-        if (a.gshunt != 0.0) hipLaunchKernelGGL(sp_diag_shunt_kernel, gn, b256, 0, st, a, d);
-        if (a.mode == MODE_DC) hipLaunchKernelGGL(sp_norms_kernel, dim3(1), dim3(1024), 0, st, a, d, 0);
+      {
+        const SparseDev d = sparse_dev(which); const int* al = sp_act[1].p;
+        hipLaunchKernelGGL(sp_eval_kernel, grid(gd, act.size()), dim3(64), 0, st, a, d, al);
+        hipLaunchKernelGGL(sp_assemble_kernel, grid(ga, act.size()), b256, 0, st, a, d, al);
+        if (a.gshunt != 0.0) hipLaunchKernelGGL(sp_diag_shunt_kernel, grid(gn, act.size()), b256, 0, st, a, d, al);
+        if (a.mode == MODE_DC) hipLaunchKernelGGL(sp_norms_kernel, grid(1, act.size()), b1k, 0, st, a, d, al, 0);
         n_launch += 2;
       }
       if (a.mode == MODE_EVAL) { for (int sm : act) status[sm] = 0; break; }
       if (a.mode == MODE_DC) {
-        int rc = sp_sync(); if (rc != CH_OK) return rc;
+        rc = sp_sync(); if (rc != CH_OK) return rc;
         std::vector<int> keep;
         for (int sm : act) {
           fnorm[sm] = h_red[(size_t)sm * 8];
@@ -694,36 +720,44 @@ struct ch_circuit {
           else if (fnorm[sm] < a.dc_abstol) status[sm] = 0;
           else keep.push_back(sm);
         }
-        act.swap(keep);
+        if (keep.size() != act.size()) { act.swap(keep); if (!act.empty()) { rc = stage_list(1, act); if (rc != CH_OK) return rc; } }
         if (act.empty()) break;
       }
       if (it == maxit) break;
       bool fresh = false;
-      if (!plan[which].valid) { int rc = sparse_plan_from_current(which, act[0]); if (rc != CH_OK) { for (int sm : act) status[sm] = 2; act.clear(); break; } fresh = true; }
+      if (!plan[which].valid) { rc = sparse_plan_from_current(which, act[0]); if (rc != CH_OK) { for (int sm : act) status[sm] = 2; act.clear(); break; } fresh = true; }
       std::vector<int> work = act;   // samples whose factorisation is still to be done in this iteration
+      const int* wl = sp_act[1].p;
       for (int attempt = 0; attempt < 2 && !work.empty(); ++attempt) {
-        for (int sm : work) {
-          const SparseDev d = sparse_dev(which, sm);
-          hipLaunchKernelGGL(sp_lu_solve_kernel, dim3(1), dim3(1024), 0, st, d);
-          if (damp) hipLaunchKernelGGL(sp_norms_kernel, dim3(1), dim3(1024), 0, st, a, d, 1);
-        }
+        const SparseDev d = sparse_dev(which);
+        hipLaunchKernelGGL(sp_lu_solve_kernel, grid(1, work.size()), b1k, 0, st, d, wl);
+        const double* sc = nullptr;
         if (damp) {
-          int rc = sp_sync(); if (rc != CH_OK) return rc;
+          hipLaunchKernelGGL(sp_norms_kernel, grid(1, work.size()), b1k, 0, st, a, d, wl, 1);
+          rc = sp_sync(); if (rc != CH_OK) return rc;
           for (int sm : work) { scale[sm] = 1.0; const double mx = h_red[(size_t)sm * 8 + 1]; if (!h_flag[(size_t)sm * 2] && mx > a.dv_max) scale[sm] = a.dv_max / mx; }
+          g_arena = &arena;
+          HIPCHK(sp_scale.alloc((size_t)S));
+          std::memcpy(h_scale, scale.data(), (size_t)S * sizeof(double));
+          HIPCHK(hipMemcpyAsync(sp_scale.p, h_scale, (size_t)S * sizeof(double), hipMemcpyHostToDevice, st));
+          sc = sp_scale.p;
         }
-        for (int sm : work) hipLaunchKernelGGL(sp_update_kernel, dim3(1), dim3(1024), 0, st, a, sparse_dev(which, sm), damp ? scale[sm] : 1.0);  // no-op when the factorisation failed
-        int rc = sp_sync(); if (rc != CH_OK) return rc;
-        n_launch += 2 * (long)work.size();
+        hipLaunchKernelGGL(sp_update_kernel, grid(1, work.size()), b1k, 0, st, a, d, wl, sc);  // no-op where the factorisation failed
+        rc = sp_sync(); if (rc != CH_OK) return rc;
+        n_launch += 2;
         std::vector<int> failed;
         for (int sm : work) if (h_flag[(size_t)sm * 2]) failed.push_back(sm);
         if (failed.empty()) break;
         // a static pivot became zero: re-analyse once with the current values of the first failing sample (KLU would
         // re-pivot here too) and redo the failing samples; the others have already taken their step
-        if (fresh || attempt == 1) { for (int sm : failed) status[sm] = 2; work.clear(); act.erase(std::remove_if(act.begin(), act.end(), [&](int q) { return status[q] == 2; }), act.end()); break; }
+        auto drop_failed = [&]() { for (int sm : failed) status[sm] = 2; act.erase(std::remove_if(act.begin(), act.end(), [&](int q) { return status[q] == 2; }), act.end()); };
+        if (fresh || attempt == 1) { drop_failed(); work.clear(); break; }
         rc = sparse_plan_from_current(which, failed[0]);
-        if (rc != CH_OK) { for (int sm : failed) status[sm] = 2; act.erase(std::remove_if(act.begin(), act.end(), [&](int q) { return status[q] == 2; }), act.end()); break; }
+        if (rc != CH_OK) { drop_failed(); break; }
         fresh = true;
         work.swap(failed);
+        rc = stage_list(2, work); if (rc != CH_OK) return rc;
+        wl = sp_act[2].p;
       }
       std::vector<int> keep;
       for (int sm : act) {
@@ -740,14 +774,12 @@ struct ch_circuit {
         }
         keep.push_back(sm);
       }
-      act.swap(keep);
+      if (keep.size() != act.size()) { act.swap(keep); if (!act.empty()) { rc = stage_list(1, act); if (rc != CH_OK) return rc; } }
     }
-    for (int sm : todo) {
-      if (a.mode == MODE_TRAN && status[sm] == 0) sp_rate_v[sm] = iters[sm] >= 2 ? std::min(1.0, std::max(rate_new[sm], 1e-4)) : std::min(1.0, rate_prev[sm] * 1.5);
-      hipLaunchKernelGGL(sp_commit_kernel, dim3(1), dim3(1024), 0, st, a, sparse_dev(which, sm), (a.mode == MODE_TRAN) ? 0 : 1);
-    }
-    int rc = sp_sync(); if (rc != CH_OK) return rc;
-    n_launch += (long)todo.size();
+    for (int sm : todo) if (a.mode == MODE_TRAN && status[sm] == 0) sp_rate_v[sm] = iters[sm] >= 2 ? std::min(1.0, std::max(rate_new[sm], 1e-4)) : std::min(1.0, rate_prev[sm] * 1.5);
+    hipLaunchKernelGGL(sp_commit_kernel, grid(1, todo.size()), b1k, 0, st, a, sparse_dev(which), (const int*)sp_act[0].p, (a.mode == MODE_TRAN) ? 0 : 1);
+    rc = sp_sync(); if (rc != CH_OK) return rc;
+    n_launch += 1;
     for (int sm : todo) {
       sp_status_v[sm] = status[sm];
       if (status[sm] != 0) ++out.n_fail;

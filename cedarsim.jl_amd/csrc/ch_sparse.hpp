@@ -194,7 +194,8 @@ struct SparseDev {
   const int* lrow_ptr; const int* l_pos; const int* l_k; const int* l_upd_ptr; const int* upd_dst; const int* upd_src;
   const int* urow_ptr; const int* u_pos; const int* u_col;
   int n, nnz, nnz_lu, n_lvl, n_ulvl, n_dev;
-  int s; long xofs;                // sample handled by this launch; its offset s*n inside a slot of the state ring
+  int s; long xofs;                // sample handled by this workgroup; its offset s*n inside a slot of the state ring
+  long st_stage, st_nnz, st_lu, st_n;  // per-sample strides of the work arrays (the struct is built for sample 0)
   int stride, q_ofs, c_ofs, wide;  // stamp record layout (40/4/16 narrow, 144/8/64 with compiled Verilog-A devices)
   // work arrays
   double* stage; double* Aval; double* Cval; double* LUv; double* F; double* Q; double* rhs; double* y; double* dx;
@@ -204,8 +205,21 @@ struct SparseDev {
   int* dflag;    // device memory: [1] singular flag of the last factorisation (read by the update kernel)
 };
 
+// Every kernel of this path runs all active samples in one launch: blockIdx.y walks the list `act` of sample indices and
+// the workgroup works on that sample's slices of the arrays.
+__device__ __forceinline__ SparseDev sp_pick(SparseDev d, const int* act) {
+  const int sm = act[blockIdx.y];
+  d.s = sm; d.xofs = (long)sm * d.st_n;
+  d.stage += sm * d.st_stage; d.Aval += sm * d.st_nnz; d.Cval += sm * d.st_nnz; if (d.LUv) d.LUv += sm * d.st_lu;
+  d.F += sm * d.st_n; d.Q += sm * d.st_n; d.rhs += sm * d.st_n; d.y += sm * d.st_n; d.dx += sm * d.st_n;
+  d.xcur += sm * d.st_n; d.xpred += sm * d.st_n; d.hq += sm * d.st_n; d.w += sm * d.st_n; d.qn += sm * d.st_n;
+  d.red += (long)sm * 8; d.flag += (long)sm * 2; d.dflag += sm;
+  return d;
+}
+
 // predictor / history term / Newton weights
-__global__ void sp_predict_kernel(const NewtonArgs a, const SparseDev d) {
+__global__ void sp_predict_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
+  const SparseDev d = sp_pick(d0, act);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n) return;
   const double x0 = a.X[(long)a.hist_slot[0] * a.slot_stride + d.xofs + i];
@@ -220,7 +234,8 @@ __global__ void sp_predict_kernel(const NewtonArgs a, const SparseDev d) {
 }
 
 // one thread per device instance: stamps to HBM
-__global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const SparseDev d) {
+__global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
+  const SparseDev d = sp_pick(d0, act);
   const int dev = blockIdx.x * blockDim.x + threadIdx.x;
   if (dev >= d.n_dev) return;
   const int sm = d.s;
@@ -281,7 +296,8 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
 }
 
 // CSR gather assembly: one thread per nnz and per row
-__global__ void sp_assemble_kernel(const NewtonArgs a, const SparseDev d) {
+__global__ void sp_assemble_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
+  const SparseDev d = sp_pick(d0, act);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
   if (i < d.nnz) {
@@ -298,14 +314,16 @@ __global__ void sp_assemble_kernel(const NewtonArgs a, const SparseDev d) {
     d.F[i] = F; d.rhs[i] = -F;
   }
 }
-__global__ void sp_diag_shunt_kernel(const NewtonArgs a, const SparseDev d) {  // gmin stepping: + gshunt on node diagonals
+__global__ void sp_diag_shunt_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {  // gmin stepping: + gshunt on node diagonals
+  const SparseDev d = sp_pick(d0, act);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n || (a.dmask[i] & 2)) return;
   for (int p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) if (d.colidx[p] == i) d.Aval[p] += a.gshunt;
 }
 
 // Numeric re-factorisation + both triangular solves inside ONE workgroup.
-__global__ __launch_bounds__(1024) void sp_lu_solve_kernel(const SparseDev d) {
+__global__ __launch_bounds__(1024) void sp_lu_solve_kernel(const SparseDev d0, const int* act) {
+  const SparseDev d = sp_pick(d0, act);
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
   for (int i = tid; i < d.nnz_lu; i += nthr) d.LUv[i] = 0.0;
   __syncthreads();
@@ -358,7 +376,8 @@ __global__ __launch_bounds__(1024) void sp_lu_solve_kernel(const SparseDev d) {
 }
 
 // reductions: red[0]=max|F|, red[1]=max|dx| over node rows, red[2]=sum (dx*w)^2, red[3]=bad flag
-__global__ __launch_bounds__(1024) void sp_norms_kernel(const NewtonArgs a, const SparseDev d, int what) {
+__global__ __launch_bounds__(1024) void sp_norms_kernel(const NewtonArgs a, const SparseDev d0, const int* act, int what) {
+  const SparseDev d = sp_pick(d0, act);
   __shared__ double s0[1024], s1[1024], s2[1024];
   const int t = threadIdx.x;
   double m0 = 0, m1 = 0, m2 = 0;
@@ -373,7 +392,9 @@ __global__ __launch_bounds__(1024) void sp_norms_kernel(const NewtonArgs a, cons
 }
 
 // x += scale*dx ; qn = Q + C*(scale*dx) ; e2 = sum (scale*dx*w)^2 ; bad flag
-__global__ __launch_bounds__(1024) void sp_update_kernel(const NewtonArgs a, const SparseDev d, double scale) {
+__global__ __launch_bounds__(1024) void sp_update_kernel(const NewtonArgs a, const SparseDev d0, const int* act, const double* scale_v) {
+  const SparseDev d = sp_pick(d0, act);
+  const double scale = scale_v ? scale_v[d.s] : 1.0;
   __shared__ double s2[1024]; __shared__ int sbad;
   const int t = threadIdx.x;
   if (d.dflag[0]) return;  // factorisation failed: leave the iterate untouched (the host re-analyses and retries)
@@ -395,7 +416,8 @@ __global__ __launch_bounds__(1024) void sp_update_kernel(const NewtonArgs a, con
 }
 
 // commit candidate state, observables, local-error sums: red[4..7] = e2k, e2km1, e2kp1, ndiff
-__global__ __launch_bounds__(1024) void sp_commit_kernel(const NewtonArgs a, const SparseDev d, int use_q_of_eval) {
+__global__ __launch_bounds__(1024) void sp_commit_kernel(const NewtonArgs a, const SparseDev d0, const int* act, int use_q_of_eval) {
+  const SparseDev d = sp_pick(d0, act);
   __shared__ double s0[1024], s1[1024], s2[1024], s3[1024];
   const int t = threadIdx.x;
   double e2k = 0, e2m = 0, e2p = 0, nd = 0;
