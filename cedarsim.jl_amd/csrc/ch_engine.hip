@@ -643,6 +643,24 @@ struct ch_circuit {
     HIPCHK(pd.LUv.alloc((size_t)S * (size_t)P.nnz_lu));
     return CH_OK;
   }
+  // Small-signal analyses see the circuit as dense blocks: the Jacobian blocks of the fused path, or — on the sparse path —
+  // the whole system as one block per sample (up to 96 unknowns: 2·n·(n+1) doubles of LDS for the complex LU)
+  DevBuf<BlockMeta> d_bmeta_all;
+  int ac_ncomp() const { return path == 2 ? 1 : A.n_comp; }
+  int ac_ds() const { return path == 2 ? A.n_unk : A.max_nc; }
+  int ac_comp_of(int u) const { return path == 2 ? 0 : (int)(std::upper_bound(A.comp_uofs.begin(), A.comp_uofs.end(), u) - A.comp_uofs.begin()) - 1; }
+  int ac_uofs(int comp) const { return path == 2 ? 0 : A.comp_uofs[comp]; }
+  int ac_nc(int comp) const { return path == 2 ? A.n_unk : A.comp_nc[comp]; }
+  int ac_dofs(int comp) const { return path == 2 ? 0 : A.comp_dofs[comp]; }
+  int ac_ndev(int comp) const { return path == 2 ? (int)A.edev.size() : A.comp_ndev[comp]; }
+  const BlockMeta* ac_bmeta() {
+    if (path != 2) return d_bmeta.p;
+    BlockMeta b; std::memset(&b, 0, sizeof(b)); b.uofs = 0; b.dofs = 0; b.cm.nc = A.n_unk; b.cm.ndev = (int)A.edev.size();
+    std::vector<BlockMeta> v(1, b);
+    g_arena = &arena;
+    if (d_bmeta_all.upload(v, ctx->stream) != hipSuccess) return nullptr;
+    return d_bmeta_all.p;
+  }
   int sp_sync() {
     hipStream_t st = ctx->stream;
     hipError_t q = hipErrorNotReady;
@@ -1389,12 +1407,12 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
 static int ac_linearise(ch_circuit* c, const ch_dc_opts* o, ch_stats* st, bool want_b) {
   int rc = c->finalize_params();
   if (rc != CH_OK) return rc;
-  if (c->path != 1) { c->set_err("AC / noise analysis needs Jacobian blocks that fit one CU (the sparse path has no complex LU yet)"); return CH_ERR_UNSUPPORTED; }
+  if (c->path == 2 && c->A.n_unk > 96) { c->set_err("AC / noise analysis: the coupled system has more than 96 unknowns (the complex LU works in one CU's LDS)"); return CH_ERR_UNSUPPORTED; }
   g_arena = &c->arena;
   rc = c->dc_solve(*o, 0, nullptr, st);
   if (rc != CH_OK) return rc;
   const Analysis& A = c->A;
-  const int S = c->S, nblk = A.n_comp * S, ds = A.max_nc;
+  const int S = c->S, nblk = c->ac_ncomp() * S, ds = c->ac_ds();
   const size_t nA = (size_t)nblk * ds * ds, nF = (size_t)nblk * ds;
   if (c->d_dumpG.alloc(nA) != hipSuccess || c->d_dumpC.alloc(nA) != hipSuccess || c->d_dumpF0.alloc(nF) != hipSuccess ||
       c->d_dumpF.alloc(nF) != hipSuccess || c->d_dumpQ.alloc(nF) != hipSuccess || c->d_dumpA.alloc(nA) != hipSuccess) return CH_ERR_DEVICE;
@@ -1411,6 +1429,12 @@ static int ac_linearise(ch_circuit* c, const ch_dc_opts* o, ch_stats* st, bool w
     Summary sm;
     rc = c->run_newton(a, nullptr, sm);
     if (rc != CH_OK) return rc;
+    if (c->path == 2) {   // the sparse evaluation left G (alpha0 = 0), C and F in CSR / vector form: expand to the dense blocks
+      const int n = A.n_unk, nnz = (int)c->h_colidx.size();
+      hipLaunchKernelGGL(csr_to_dense_kernel, dim3((n + 63) / 64, S), dim3(64), 0, c->ctx->stream, (const int*)c->sp_rowptr.p, (const int*)c->sp_colidx.p,
+                         (const double*)c->sp_Aval.p, (const double*)c->sp_Cval.p, (const double*)c->sp_F.p, n, nnz, S, c->d_dumpG.p, c->d_dumpC.p,
+                         pass == 0 ? c->d_dumpF0.p : c->d_dumpF.p, pass == 0 ? 1 : 0);
+    }
   }
   if (want_b) {  // b = F0 - F1 (device side, in place in d_dumpF)
     hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((nF + 255) / 256)), dim3(256), 0, c->ctx->stream, c->d_dumpF.p, (const double*)c->d_dumpF0.p, (long)nF);
@@ -1438,13 +1462,14 @@ int ch_ac(ch_circuit* c, const ch_dc_opts* o, int32_t n_freq, const double* freq
   st.dc_seconds = std::chrono::duration<double>(hclock::now() - t0).count();
   if (rc != CH_OK) { if (stats) *stats = st; return rc; }
   const Analysis& A = c->A;
-  const int S = c->S, nblk = A.n_comp * S, ds = A.max_nc;
+  const int S = c->S, nblk = c->ac_ncomp() * S, ds = c->ac_ds();
   g_arena = &c->arena;
   rc = upload_omega(c, n_freq, freqs_hz); if (rc != CH_OK) return rc;
   const size_t nx = (size_t)S * n_freq * A.n_unk * 2;
   if (c->d_xac.alloc(nx) != hipSuccess) return CH_ERR_DEVICE;
   AcArgs a; std::memset(&a, 0, sizeof(a));
-  a.bmeta = c->d_bmeta.p; a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = c->d_dumpF.p; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = A.n_comp;
+  a.bmeta = c->ac_bmeta(); a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = c->d_dumpF.p; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = c->ac_ncomp();
+  if (!a.bmeta) return CH_ERR_DEVICE;
   a.omega = c->d_omega.p; a.x_out = c->d_xac.p; a.noise = 0; a.fail = c->d_acfail.p;
   const size_t lds = (size_t)2 * ds * (ds + 1) * sizeof(double);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ac_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1487,18 +1512,18 @@ int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_i
   int rc = ac_linearise(c, o, &st, false);
   st.dc_seconds = std::chrono::duration<double>(hclock::now() - t0).count();
   if (rc != CH_OK) { if (stats) *stats = st; return rc; }
-  const int S = c->S, ds = A.max_nc;
+  const int S = c->S, ds = c->ac_ds();
   if (u_out < 0) {  // a node held by ideal sources carries no noise
     std::fill(psd_out, psd_out + (size_t)S * n_freq, 0.0);
     if (stats) *stats = st;
     return CH_OK;
   }
-  const int comp = (int)(std::upper_bound(A.comp_uofs.begin(), A.comp_uofs.end(), u_out) - A.comp_uofs.begin()) - 1;
-  const int uofs = A.comp_uofs[comp], ncb = A.comp_nc[comp];
+  const int comp = c->ac_comp_of(u_out);
+  const int uofs = c->ac_uofs(comp), ncb = c->ac_nc(comp);
   g_arena = &c->arena;
   rc = upload_omega(c, n_freq, freqs_hz); if (rc != CH_OK) return rc;
   // noise table of the output block at the operating point (device side)
-  const int ndev_b = A.comp_ndev[comp], n_tab = ndev_b * va::MAX_NOISE;
+  const int ndev_b = c->ac_ndev(comp), n_tab = ndev_b * va::MAX_NOISE;
   if (c->d_noise_a.alloc((size_t)S * n_tab) != hipSuccess || c->d_noise_b.alloc((size_t)S * n_tab) != hipSuccess ||
       c->d_noise_pwr.alloc((size_t)S * n_tab) != hipSuccess || c->d_noise_exp.alloc((size_t)S * n_tab) != hipSuccess ||
       c->d_psd.alloc((size_t)S * n_freq) != hipSuccess) return CH_ERR_DEVICE;
@@ -1514,12 +1539,13 @@ int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_i
     t.dpar = c->d_dpar.p; t.dmult = c->d_dmult.p; t.vapar = c->d_vapar.p; t.va_stride = c->base.va_stride; t.temp_s = c->d_temp.p; t.gmin_s = c->d_gmin.p;
     t.X = c->d_X.p; t.kv = c->d_kv.p;  // slot 0 holds the operating point
     t.Spar = c->Spar; t.Stemp = c->Stemp; t.Sgmin = c->Sgmin; t.Ssrc = c->Ssrc; t.nk = (int)A.known.size(); t.S = S; t.n_unk = A.n_unk;
-    t.dofs = A.comp_dofs[comp]; t.ndev = ndev_b; t.uofs = uofs; t.nc = ncb;
+    t.dofs = c->ac_dofs(comp); t.ndev = ndev_b; t.uofs = uofs; t.nc = ncb;
     t.na = c->d_noise_a.p; t.nb = c->d_noise_b.p; t.pwr = c->d_noise_pwr.p; t.ex = c->d_noise_exp.p;
     hipLaunchKernelGGL(noise_table_kernel, dim3((ndev_b * S + 63) / 64), dim3(64), 0, c->ctx->stream, t);
   }
   AcArgs a; std::memset(&a, 0, sizeof(a));
-  a.bmeta = c->d_bmeta.p; a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = nullptr; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = A.n_comp;
+  a.bmeta = c->ac_bmeta(); a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = nullptr; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = c->ac_ncomp();
+  if (!a.bmeta) return CH_ERR_DEVICE;
   a.omega = c->d_omega.p; a.noise = 1; a.comp_out = comp; a.row_out = u_out - uofs; a.n_noise = n_tab;
   a.noise_a = c->d_noise_a.p; a.noise_b = c->d_noise_b.p; a.noise_pwr = c->d_noise_pwr.p; a.noise_exp = c->d_noise_exp.p;
   a.psd_out = c->d_psd.p; a.fail = c->d_acfail.p;

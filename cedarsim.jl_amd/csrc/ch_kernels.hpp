@@ -941,6 +941,19 @@ __global__ void va_opvars_kernel(int mod, const double* P, const double* v, doub
   va_gen::opvars(mod, P, vv, env, op);
 }
 
+// sparse path -> dense small-signal blocks: CSR values of G and C (one system per sample) into [S][n][n], F into [S][n]
+__global__ void csr_to_dense_kernel(const int* rowptr, const int* colidx, const double* Aval, const double* Cval, const double* F,
+                                    int n, int nnz, int S, double* G, double* C, double* Fd, int fill_gc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, sm = blockIdx.y;
+  if (i >= n || sm >= S) return;
+  if (fill_gc) {
+    double* g = G + ((long)sm * n + i) * n; double* c = C + ((long)sm * n + i) * n;
+    for (int j = 0; j < n; ++j) { g[j] = 0.0; c[j] = 0.0; }
+    for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) { g[colidx[p]] = Aval[(long)sm * nnz + p]; c[colidx[p]] = Cval[(long)sm * nnz + p]; }
+  }
+  Fd[(long)sm * n + i] = F[(long)sm * n + i];
+}
+
 // y = x - y (AC right-hand side b = F(src) - F(src + ac))
 __global__ void axpby_kernel(double* y, const double* x, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -183,3 +183,44 @@ def test_va_noise_sources_white_and_flicker(E):
     i_each = 0.5e-3                                       # two parallel instances share the bias
     s_i = 2.0 * (4 * k * T / R + 1e-10 * i_each ** 2 / f ** 1.2)
     assert np.allclose(psd[0], s_i * (R / 2.0) ** 2, rtol=1e-10)
+
+
+def _self_biased_chain(n_stages):
+    """AC-coupled chain of self-biased BSIM-CMG inverters (1 MOhm feedback, 1 fF coupling): every stage sits at its switching
+    point, so the DC point is easy and the small-signal transfer is large; the coupling capacitors make it ONE Jacobian block."""
+    from cedarsim_jl_amd import parse_spice
+    cards = json.load(open(os.path.join(HERE, "golden", "asap7_tt_lvt_cards.json")))["cards"]
+    lines = ["* chain", "VVDD VDD 0 0.7", "VIN src 0 DC 0 AC 1", "cc0 src i1 1e-15"]
+    for k in range(1, n_stages + 1):
+        lines += ["mn%d o%d i%d 0 0 nmos_lvt" % (k, k, k), "mp%d o%d i%d VDD VDD pmos_lvt" % (k, k, k), "rf%d o%d i%d 1e6" % (k, k, k)]
+        if k < n_stages:
+            lines.append("cc%d o%d i%d 1e-15" % (k, k, k + 1))
+    lines.append("cl o%d 0 1e-15" % n_stages)
+    nl = parse_spice("\n".join(lines) + "\n.END\n")
+    nl.add_model_cards(cards)
+    return nl.build()
+
+
+def test_ac_and_noise_on_the_sparse_path_match_oracle(E, O):
+    """A coupled system too large for the fused kernel (13 self-biased BSIM-CMG stages, 81 unknowns with the AC source):
+    the sparse path evaluates G and C, which are expanded to one dense block per sample for the complex LU."""
+    from cedarsim_jl_amd.va.registry import load_modules
+    if "bsimcmg" not in load_modules()[1]:
+        pytest.skip("bsimcmg was not in the model library build")
+    c = _self_biased_chain(13)
+    c.observe_all_nodes()
+    f = acdec(4, 1e6, 1e12)
+    eng = E(c, small_signal=True)
+    rc, xe, st = eng.ac(f, dc_opts(abstol=1e-11))
+    assert rc == 0, eng.ctx.last_error()
+    assert eng.info()["path"] == 2 and 64 < eng.info()["n_unknowns"] <= 96
+    rc_o, xo = O(c).ac(f, dc_opts(abstol=1e-11))
+    assert rc_o == 0
+    for node in ("o1", "o6", "o13"):
+        a, b = xe[0][:, c._n(node) - 1], xo[:, c._n(node) - 1]
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(b).max())), node
+    assert np.abs(xe[0][:, c._n("o13") - 1]).max() > 10.0      # the chain amplifies in its pass band
+    rc, pe, st = E(c).noise(0, c._n("o3"), f, dc_opts(abstol=1e-11))
+    rc_o, po = O(c).noise(c._n("o3") - 1, f, dc_opts(abstol=1e-11))
+    assert rc == 0 and rc_o == 0 and np.all(pe[0] > 0)
+    assert np.allclose(pe[0], po, rtol=1e-6)
