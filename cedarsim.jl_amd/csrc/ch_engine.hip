@@ -468,7 +468,7 @@ struct ch_circuit {
         mc_list.insert(mc_list.end(), seen.begin(), seen.end());
         max_mc = std::max(max_mc, mc_n[k]);
       }
-      if (max_mc > 64 && false) { set_err("a Jacobian block uses more than 64 distinct MOSFET classes"); return CH_ERR_UNSUPPORTED; }
+      // (a block with more than 64 distinct MOSFET classes takes the sparse path: see the path decision below)
       std::vector<BlockMeta> bmv(A.n_comp);
       for (int k = 0; k < A.n_comp; ++k) {
         BlockMeta& b = bmv[k]; std::memset(&b, 0, sizeof(b));
