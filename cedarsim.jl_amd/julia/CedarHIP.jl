@@ -9,7 +9,7 @@ using CedarSim: DefaultSim, ParamSim, SimSpec, ParallelInstances, Named
 using CassetteOverlay, Base.Experimental: @MethodTable, @overlay
 
 const lib = joinpath(@__DIR__, "..", "lib", "libcedarhip.so")
-const CH_DEV = (R=1, C=2, L=3, V=4, I=5, VCVS=6, VCCS=7, MOS=8)
+const CH_DEV = (R=1, C=2, L=3, V=4, I=5, VCVS=6, VCCS=7, MOS=8, VA=9)   # CH_DEV_NNODE = 8 node slots per device
 
 # ---- struct mirrors (field order == include/cedarhip.h) ----
 struct ChDesc
@@ -36,7 +36,7 @@ end
 # Same technique as AliasInterp (src/aliasextract.jl:10-39): re-run the circuit with fake nets.
 mutable struct StampTable
     nets::Dict{Symbol,Int32}
-    kind::Vector{Int32}; node::Vector{NTuple{4,Int32}}; par::Vector{NTuple{8,Float64}}; mult::Vector{Float64}
+    kind::Vector{Int32}; node::Vector{NTuple{8,Int32}}; par::Vector{NTuple{8,Float64}}; mult::Vector{Float64}
     names::Vector{Symbol}
     sources::Vector{Any}; models::Vector{Any}
 end
@@ -48,7 +48,7 @@ struct FakeNet; id::Int32; multiplier::Float64; end
 #   instance fields via modelparams(), src/spectre.jl:290-295) …
 
 function stamp_extract(sim)
-    tbl = StampTable(Dict{Symbol,Int32}(), Int32[], NTuple{4,Int32}[], NTuple{8,Float64}[], Float64[], Symbol[], Any[], Any[])
+    tbl = StampTable(Dict{Symbol,Int32}(), Int32[], NTuple{8,Int32}[], NTuple{8,Float64}[], Float64[], Symbol[], Any[], Any[])
     # with(TABLE => tbl) do; StampPass()(sim.circuit); end
     tbl
 end
