@@ -17,7 +17,7 @@ using namespace chip;
 int main() {
   std::mt19937 rng(42);
   long ok = 0, err = 0;
-  for (int trial = 0; trial < 6000; ++trial) {
+  for (int trial = 0; trial < 3000; ++trial) {
     const int n_nodes = 1 + rng() % 12;
     const int n_src = 1 + rng() % 4;
     std::vector<HSource> src(n_src);

@@ -19,7 +19,7 @@ using namespace chip;
 int main() {
   std::mt19937 rng(123);
   int nfail = 0, nsing = 0, ntot = 0;
-  for (int trial = 0; trial < 4000; ++trial) {
+  for (int trial = 0; trial < 1200; ++trial) {
     int n = 1 + rng() % 14;
     double dens = (rng() % 100) / 100.0;
     std::vector<int> rp(1, 0), ci; std::vector<double> av;
