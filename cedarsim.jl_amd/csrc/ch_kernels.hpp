@@ -327,7 +327,7 @@ __device__ inline bool lu_solve_lds(double* A, int lda, int nc, int lane) {
   return true;
 }
 
-// LDS layout (doubles): st[ndev*40] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq dx w qn [8*nc] | kvl[nk] svl[nsrc]
+// LDS layout (doubles): st[ndev*40] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq dx w qn pm pp [10*nc] | kvl[nk] svl[nsrc]
 //                       | ints: mptr[nc*nc+1] vptr[nc+1] slots[nslots] | u16: msrc[] vsrc[]
 template <int NC, bool WIDE = false>
 __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a) {
@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
   double* xl = Cm + (size_t)nc * nc;
   double* xp = xl + nc; double* Fv = xp + nc; double* Qv = Fv + nc; double* hq = Qv + nc;
   double* dxv = hq + nc; double* wv = dxv + nc; double* qn = wv + nc;
-  double* kvl = qn + nc; double* svl = kvl + a.nk;
+  double* pm = qn + nc; double* pp = pm + nc;          // predictors of order k-1 / k+1 (local-error estimates of the epilogue)
+  double* kvl = pp + nc; double* svl = kvl + a.nk;
   double* pl = svl + a.nsrc;                       // [max_mc][B4I_COUNT] packed BSIM4 columns of this block's classes
   int* mptr = (int*)(pl + (size_t)a.max_mc * B4I_COUNT);  // start of the class blob copy
   int* vptr = mptr + (nc * nc + 1);
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       const int* src = a.blob + cm.blob_ofs;
       const int nb = cm.blob_ints, total = bm.mc_n * B4I_COUNT;
       int bv[8]; double pv[PB]; double x0 = 0.0, xv[7], qv[5];
+      const int nxh = max(a.npred, max(a.nkm1, a.nkp1));   // history points any of the three predictors needs
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int i = tid + u * 64; bv[u] = src[i < nb ? i : nb - 1]; }
       if (total > 0) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       x0 = X0[iu];
       if (a.mode == MODE_TRAN) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) xv[j] = a.X[(long)a.hist_slot[j < a.npred ? j : 0] * a.slot_stride + sofs + iu];
+        for (int j = 0; j < 7; ++j) xv[j] = a.X[(long)a.hist_slot[j < nxh ? j : 0] * a.slot_stride + sofs + iu];
 #pragma unroll
         for (int j = 0; j < 5; ++j) qv[j] = a.Qh[(long)a.hist_slot[j < a.k ? j : 0] * a.slot_stride + sofs + iu];
       }
@@ -421,6 +423,10 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
           for (int j = 0; j < 7; ++j) p += (j < a.npred ? a.wpred[j + 1] : 0.0) * xv[j];
 #pragma unroll
           for (int j = 0; j < 5; ++j) h += (j < a.k ? a.alpha[j + 1] : 0.0) * qv[j];
+          double m1 = 0.0, p1 = 0.0;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) { m1 += (j < a.nkm1 ? a.wkm1[j + 1] : 0.0) * xv[j]; p1 += (j < a.nkp1 ? a.wkp1[j + 1] : 0.0) * xv[j]; }
+          pm[tid] = m1; pp[tid] = p1;
         }
         xp[tid] = p; xl[tid] = p; hq[tid] = h; qn[tid] = 0.0;
         wv[tid] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
@@ -472,13 +478,16 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       double p = x0, h = 0.0;
       if (a.mode == MODE_TRAN) {
         double xv[7], qv[5];  // all history loads are issued before any is used
+        const int nxh2 = max(a.npred, max(a.nkm1, a.nkp1));
 #pragma unroll
-        for (int j = 0; j < 7; ++j) xv[j] = a.X[(long)a.hist_slot[j < a.npred ? j : 0] * a.slot_stride + sofs + i];
+        for (int j = 0; j < 7; ++j) xv[j] = a.X[(long)a.hist_slot[j < nxh2 ? j : 0] * a.slot_stride + sofs + i];
 #pragma unroll
         for (int j = 0; j < 5; ++j) qv[j] = a.Qh[(long)a.hist_slot[j < a.k ? j : 0] * a.slot_stride + sofs + i];
         p = 0.0;
+        double m1 = 0.0, p1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) p += (j < a.npred ? a.wpred[j + 1] : 0.0) * xv[j];
+        for (int j = 0; j < 7; ++j) { p += (j < a.npred ? a.wpred[j + 1] : 0.0) * xv[j]; m1 += (j < a.nkm1 ? a.wkm1[j + 1] : 0.0) * xv[j]; p1 += (j < a.nkp1 ? a.wkp1[j + 1] : 0.0) * xv[j]; }
+        pm[i] = m1; pp[i] = p1;
 #pragma unroll
         for (int j = 0; j < 5; ++j) h += (j < a.k ? a.alpha[j + 1] : 0.0) * qv[j];
       }
@@ -652,8 +661,8 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
           const double w = 1.0 / (a.reltol * fmax(fabs(x0), fabs(xn)) + a.abstol);
           ++nd;
           double t = (xn - xp[i]) * w; e2k += t * t;
-          if (a.nkm1 > 0) { double p = 0.0; for (int j = 0; j < a.nkm1; ++j) p += a.wkm1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i]; t = (xn - p) * w; e2m += t * t; }
-          if (a.nkp1 > 0) { double p = 0.0; for (int j = 0; j < a.nkp1; ++j) p += a.wkp1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + i]; t = (xn - p) * w; e2p += t * t; }
+          if (a.nkm1 > 0) { t = (xn - pm[i]) * w; e2m += t * t; }   // predictors of order k-1 / k+1 were formed in the prologue,
+          if (a.nkp1 > 0) { t = (xn - pp[i]) * w; e2p += t * t; }   // from the history values already in registers there
         }
       }
       e2k = wave_sum(e2k); e2m = wave_sum(e2m); e2p = wave_sum(e2p);
