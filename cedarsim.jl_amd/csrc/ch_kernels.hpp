@@ -382,14 +382,22 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int i = tid + u * 64; bv[u] = src[i < nb ? i : nb - 1]; }
       if (total > 0) {
+        // Element e = 64u + lane of the concatenated columns: lane 0's class j0 and offset r0 are compile-time constants of
+        // the unrolled loop and a batch of 64 elements straddles at most one class boundary, so the address is one compare
+        // and one select between two wave-uniform bases (no per-lane division / 64-bit multiply chain).
+        int cl = bm.mc[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) cl = (bm.mc_n - 1 == q) ? bm.mc[q] : cl;
+        const long last = ((long)cl * a.Smos + scol) * (long)B4I_COUNT + (B4I_COUNT - 1);
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
-          const int e0 = tid + u * 64, e = e0 < total ? e0 : total - 1;
-          const int j = e / B4I_COUNT, i = e - j * B4I_COUNT;
-          int cls = bm.mc[0];
-#pragma unroll
-          for (int q = 1; q < 8; ++q) cls = j == q ? bm.mc[q] : cls;
-          pv[u] = a.mosp[((long)cls * a.Smos + scol) * (long)B4I_COUNT + i];
+          const int j0 = (u * 64) / B4I_COUNT, r0 = u * 64 - j0 * B4I_COUNT;
+          const int ja = j0 < 8 ? j0 : 7, jb = j0 + 1 < 8 ? j0 + 1 : 7;
+          const long oa = ((long)bm.mc[ja] * a.Smos + scol) * (long)B4I_COUNT + r0;
+          const long ob = ((long)bm.mc[jb] * a.Smos + scol) * (long)B4I_COUNT + (r0 - B4I_COUNT);
+          long idx = (r0 + tid >= B4I_COUNT ? ob : oa) + tid;
+          if (tid + u * 64 >= total) idx = last;   // clamped: branch-free loads
+          pv[u] = a.mosp[idx];
         }
       }
       const int iu = tid < nc ? tid : 0;
@@ -401,19 +409,24 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
         for (int j = 0; j < 5; ++j) qv[j] = a.Qh[(long)a.hist_slot[j < a.k ? j : 0] * a.slot_stride + sofs + iu];
       }
       if (a.inline_vals) {
-#pragma unroll
-        for (int i = 0; i < KV_INLINE; ++i) if (tid == i && i < a.nk + a.nsrc) kvl[i] = a.vals_inline[i];  // kvl and svl are contiguous
+        // known-node and source values travel in the kernel arguments: lane i reads entry i of that array with one
+        // vector load from the kernarg segment (kvl and svl are contiguous in LDS)
+        typedef const double __attribute__((address_space(4)))* karg_d;
+        const karg_d kp = (karg_d)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(NewtonArgs, vals_inline));
+        const double kin = kp[tid < KV_INLINE ? tid : 0];
+        if (tid < a.nk + a.nsrc) kvl[tid] = kin;
       } else {
         const double* kg = a.kv + (long)(a.Ssrc > 1 ? s : 0) * a.nk;
         const double* sg = a.srcv + (long)(a.Ssrc > 1 ? s : 0) * a.nsrc;
         for (int i = tid; i < a.nk; i += nthr) kvl[i] = kg[i];
         for (int i = tid; i < a.nsrc; i += nthr) svl[i] = sg[i];
       }
+      // branch-free stores: an out-of-range lane holds the (clamped) last element and rewrites it in place
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = tid + u * 64; if (i < nb) mptr[i] = bv[u]; }
+      for (int u = 0; u < 8; ++u) { const int i = tid + u * 64; mptr[i < nb ? i : nb - 1] = bv[u]; }
       if (total > 0) {
 #pragma unroll
-        for (int u = 0; u < PB; ++u) { const int e = tid + u * 64; if (e < total) pl[e] = pv[u]; }
+        for (int u = 0; u < PB; ++u) { const int e = tid + u * 64; pl[e < total ? e : total - 1] = pv[u]; }
       }
       if (tid < nc) {
         double p = x0, h = 0.0;
