@@ -252,47 +252,57 @@ template <int NCV> __device__ __forceinline__ int row_min_i(int v) {
   return v;
 }
 
+template <int NCV> __device__ __forceinline__ int row_max_i(int v) {
+  v = max(v, dpp_i<DPP_QP_1032>(v)); v = max(v, dpp_i<DPP_QP_2301>(v)); v = max(v, dpp_i<DPP_HALF_MIRROR>(v)); v = max(v, dpp_i<DPP_MIRROR>(v));
+  if (NCV > 16) v = max(v, __shfl_xor(v, 16));
+  return v;
+}
+
 // In-register dense LU with partial pivoting + solve by ONE wavefront: lane i owns row i of the
 // augmented matrix [A | rhs] (r[0..NC], column indices are compile-time constants).  Pivot rows
 // are not moved: a lane that has served as pivot is retired and its row is broadcast with
-// v_readlane; the pivot search is a DPP max/min reduction.  Returns false when a pivot is zero or
-// not finite.  On return lane i holds x_i in `sol` (i < nc).
+// v_readlane.  The pivot search is ONE 32-bit DPP max-reduction per step: the key is the high word
+// of |r[k]| (monotonic for non-negative doubles: exponent + 14 leading mantissa bits) with its low
+// 6 bits replaced by 63 - lane, so the largest magnitude wins and ties go to the lowest lane; the
+// winner's lane comes out of the same word.  (A 64-bit fmax reduction plus a second reduction for
+// the lane was 70 of the 130 instructions of a step.)  Returns false when the pivot column is zero
+// or not finite.  On return lane i holds x_i in `sol` (i < nc).
 template <int NC>
 __device__ __forceinline__ bool lu_solve_regs(double (&r)[NC + 1], int nc, int lane, double& sol) {
   bool done = lane >= nc;
   int mystep = -1;       // elimination step at which this lane's row became the pivot row
+  double ipiv = 0.0;     // reciprocal of this lane's pivot
+  int piv[NC];           // pivot lane of every step (wave-uniform)
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
+    piv[k] = 0;
     if (k < nc) {
-      const double av = done ? -1.0 : fabs(r[k]);
-      const double m = row_max<NC>(av);
-      const double m0 = bcast(m, 0);
-      if (!(m0 > 0.0) || !(m0 < 1e300)) return false;
-      const int bi = __builtin_amdgcn_readfirstlane(row_min_i<NC>(av == m0 ? lane : 64));
+      const int hi = __double2hiint(r[k]) & 0x7fffffff;
+      const int key = done ? -1 : ((hi & ~63) | (63 - lane));
+      const int best = __builtin_amdgcn_readfirstlane(row_max_i<NC>(key));
+      if (best < 64 || best >= 0x7e300000) return false;   // |pivot| below the normal range, or above 2^996 / NaN
+      const int bi = 63 - (best & 63);
+      piv[k] = bi;
       const double ipk = frcp(bcast(r[k], bi));
       const double l = (!done && lane != bi) ? r[k] * ipk : 0.0;
 #pragma unroll
       for (int j = k + 1; j <= NC; ++j) r[j] = fma(-l, bcast(r[j], bi), r[j]);
-      if (lane == bi) { done = true; mystep = k; }
+      if (lane == bi) { done = true; mystep = k; ipiv = ipk; }
     }
   }
-  // back substitution: x_k lives in lane piv_lane[k]; broadcast and eliminate from the earlier pivot rows
+  // back substitution: x_k is formed in the lane whose row was the k-th pivot, broadcast, and eliminated from the earlier pivot rows
   double rhs = 0.0;
 #pragma unroll
   for (int j = 0; j <= NC; ++j) if (j == nc) rhs = r[j];
-  double x_of_step = 0.0;
+  double out = 0.0;
 #pragma unroll
   for (int k = NC - 1; k >= 0; --k) {
     if (k < nc) {
-      const int pl = __ffsll((unsigned long long)__ballot(mystep == k)) - 1;  // the lane whose row was the k-th pivot
-      const double xk = bcast(rhs, pl) * frcp(bcast(r[k], pl));
-      if (mystep == k) x_of_step = xk;
-      else if (mystep >= 0 && mystep < k) rhs = fma(-r[k], xk, rhs);
+      const double xk = bcast(rhs * ipiv, piv[k]);
+      if (lane == k) out = xk;
+      if (mystep >= 0 && mystep < k) rhs = fma(-r[k], xk, rhs);
     }
   }
-  double out = 0.0;
-#pragma unroll
-  for (int k = 0; k < NC; ++k) if (k < nc) { const double xk = bcast(x_of_step, __ffsll((unsigned long long)__ballot(mystep == k)) - 1); if (lane == k) out = xk; }
   sol = out;
   return true;
 }
