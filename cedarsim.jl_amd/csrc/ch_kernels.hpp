@@ -535,7 +535,16 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       // (2) gather (all waves)
       for (int e = tid; e < nc * nc; e += nthr) {
         double g = 0.0, cc = 0.0;
-        for (int p = mptr[e]; p < mptr[e + 1]; ++p) { const int o = msrc[p]; g += st[o]; cc += st[o + SL::CO]; }
+        // four sources in flight per trip (clamped indices, predicated adds): same summation order, a quarter of the LDS round trips
+        for (int p = mptr[e], pe = mptr[e + 1]; p < pe; p += 4) {
+          const int l = pe - 1;
+          const int o0 = msrc[p], o1 = msrc[min(p + 1, l)], o2 = msrc[min(p + 2, l)], o3 = msrc[min(p + 3, l)];
+          const double g0 = st[o0], c0 = st[o0 + SL::CO], g1 = st[o1], c1 = st[o1 + SL::CO], g2 = st[o2], c2 = st[o2 + SL::CO], g3 = st[o3], c3 = st[o3 + SL::CO];
+          g += g0; cc += c0;
+          if (p + 1 < pe) { g += g1; cc += c1; }
+          if (p + 2 < pe) { g += g2; cc += c2; }
+          if (p + 3 < pe) { g += g3; cc += c3; }
+        }
         const int r = e / nc, col = e - r * nc;
         if (r == col && a.gshunt != 0.0 && !(a.dmask[uofs + r] & 2)) g += a.gshunt;  // node rows only
         A[r * lda + col] = g + alpha0 * cc;
@@ -543,7 +552,15 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       }
       for (int i = tid; i < nc; i += nthr) {
         double f = 0.0, q = 0.0;
-        for (int p = vptr[i]; p < vptr[i + 1]; ++p) { const int o = vsrc[p]; f += st[o]; q += st[o + SL::QO]; }
+        for (int p = vptr[i], pe = vptr[i + 1]; p < pe; p += 4) {
+          const int l = pe - 1;
+          const int o0 = vsrc[p], o1 = vsrc[min(p + 1, l)], o2 = vsrc[min(p + 2, l)], o3 = vsrc[min(p + 3, l)];
+          const double f0 = st[o0], q0 = st[o0 + SL::QO], f1 = st[o1], q1 = st[o1 + SL::QO], f2 = st[o2], q2 = st[o2 + SL::QO], f3 = st[o3], q3 = st[o3 + SL::QO];
+          f += f0; q += q0;
+          if (p + 1 < pe) { f += f1; q += q1; }
+          if (p + 2 < pe) { f += f2; q += q2; }
+          if (p + 3 < pe) { f += f3; q += q3; }
+        }
         if (a.gshunt != 0.0 && !(a.dmask[uofs + i] & 2)) f += a.gshunt * xl[i];
         Qv[i] = q;
         const double F = f + alpha0 * q + hq[i];
