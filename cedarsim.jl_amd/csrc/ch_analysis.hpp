@@ -88,7 +88,7 @@ struct Analysis {
   std::vector<CompClass> classes;
   int max_nc = 0, max_ndev = 0;
   bool wide = false;               // a compiled Verilog-A device is present: stamp records are [I(8)|Q(8)|G(64)|C(64)]
-  int stride() const { return wide ? 144 : 40; }
+  int stride() const { return wide ? 145 : 41; }   // odd number of doubles per record: the lanes of a wave write different LDS banks
   int g_ofs() const { return wide ? 16 : 8; }
   int g_ld() const { return wide ? 8 : 4; }
   std::vector<int> mos_hdev;       // MOS instance -> description device index

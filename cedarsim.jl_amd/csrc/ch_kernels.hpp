@@ -132,7 +132,7 @@ struct EvalCtx {
 // stamp record layouts: narrow [I(4)|Q(4)|G(4x4)|C(4x4)] = 40 doubles; wide (a compiled Verilog-A device is
 // present) [I(8)|Q(8)|G(8x8)|C(8x8)] = 144 doubles
 template <bool WIDE> struct StampLayout {
-  static constexpr int STRIDE = WIDE ? 144 : 40, QO = WIDE ? 8 : 4, GO = WIDE ? 16 : 8, CO = WIDE ? 64 : 16, LD = WIDE ? 8 : 4;
+  static constexpr int STRIDE = WIDE ? 145 : 41, QO = WIDE ? 8 : 4, GO = WIDE ? 16 : 8, CO = WIDE ? 64 : 16, LD = WIDE ? 8 : 4;
 };
 __device__ __forceinline__ void widen_stamp(const double* t, double* st) {
 #pragma unroll
