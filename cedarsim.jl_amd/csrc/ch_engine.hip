@@ -344,7 +344,7 @@ struct ch_circuit {
     lds_doubles_fixed = 0; lds_extra_bytes = 0;
     for (size_t ci = 0; ci < A.classes.size(); ++ci) {
       const CompClass& c = A.classes[ci];
-      lds_doubles_fixed = std::max(lds_doubles_fixed, (size_t)c.ndev * A.stride() + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 10 * (size_t)c.nc);
+      lds_doubles_fixed = std::max(lds_doubles_fixed, (size_t)c.ndev * A.stride() + (size_t)c.nc * (c.nc + 1) + (size_t)c.nc * c.nc + 12 * (size_t)c.nc);
       lds_extra_bytes = std::max(lds_extra_bytes, ((size_t)cms[ci].blob_ints + 64) * 4 + 16);  // blob + the block's MOS class list
     }
     return CH_OK;

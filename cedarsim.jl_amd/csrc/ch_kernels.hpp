@@ -337,7 +337,7 @@ __device__ inline bool lu_solve_lds(double* A, int lda, int nc, int lane) {
   return true;
 }
 
-// LDS layout (doubles): st[ndev*40] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq dx w qn pm pp [10*nc] | kvl[nk] svl[nsrc]
+// LDS layout (doubles): st[ndev*41] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq dx w qn pm pp x0 dm [12*nc] | kvl[nk] svl[nsrc]
 //                       | ints: mptr[nc*nc+1] vptr[nc+1] slots[nslots] | u16: msrc[] vsrc[]
 template <int NC, bool WIDE = false>
 __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a) {
@@ -357,7 +357,9 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
   double* xp = xl + nc; double* Fv = xp + nc; double* Qv = Fv + nc; double* hq = Qv + nc;
   double* dxv = hq + nc; double* wv = dxv + nc; double* qn = wv + nc;
   double* pm = qn + nc; double* pp = pm + nc;          // predictors of order k-1 / k+1 (local-error estimates of the epilogue)
-  double* kvl = pp + nc; double* svl = kvl + a.nk;
+  double* x0l = pp + nc;                               // accepted state of the previous step (error weights of the epilogue)
+  int* dml = (int*)(x0l + nc);                         // unknown flags (bit 0 differential, bit 1 branch row): read once per launch
+  double* kvl = x0l + 2 * nc; double* svl = kvl + a.nk;
   double* pl = svl + a.nsrc;                       // [max_mc][B4I_COUNT] packed BSIM4 columns of this block's classes
   int* mptr = (int*)(pl + (size_t)a.max_mc * B4I_COUNT);  // start of the class blob copy
   int* vptr = mptr + (nc * nc + 1);
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       }
       const int iu = tid < nc ? tid : 0;
       x0 = X0[iu];
+      const int dmr = a.dmask[uofs + iu] | (a.obs_row ? (a.unk_obs[uofs + iu] + 1) << 8 : 0);   // flags | (observable row + 1) << 8
       if (a.mode == MODE_TRAN) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) xv[j] = a.X[(long)a.hist_slot[j < nxh ? j : 0] * a.slot_stride + sofs + iu];
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
         }
         xp[tid] = p; xl[tid] = p; hq[tid] = h; qn[tid] = 0.0;
         wv[tid] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
+        x0l[tid] = x0; dml[tid] = dmr;
       }
     } else {
     {
@@ -516,6 +520,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       }
       xp[i] = p; xl[i] = p; hq[i] = h; qn[i] = 0.0;
       wv[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
+      x0l[i] = x0; dml[i] = a.dmask[uofs + i] | (a.obs_row ? (a.unk_obs[uofs + i] + 1) << 8 : 0);
     }
     }
     if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 1; s_ctl[2] = 0; }
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
           if (p + 3 < pe) { g += g3; cc += c3; }
         }
         const int r = e / nc, col = e - r * nc;
-        if (r == col && a.gshunt != 0.0 && !(a.dmask[uofs + r] & 2)) g += a.gshunt;  // node rows only
+        if (r == col && a.gshunt != 0.0 && !(dml[r] & 2)) g += a.gshunt;  // node rows only
         A[r * lda + col] = g + alpha0 * cc;
         Cm[e] = cc;
       }
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
           if (p + 2 < pe) { f += f2; q += q2; }
           if (p + 3 < pe) { f += f3; q += q3; }
         }
-        if (a.gshunt != 0.0 && !(a.dmask[uofs + i] & 2)) f += a.gshunt * xl[i];
+        if (a.gshunt != 0.0 && !(dml[i] & 2)) f += a.gshunt * xl[i];
         Qv[i] = q;
         const double F = f + alpha0 * q + hq[i];
         Fv[i] = F;
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
 #pragma unroll
           for (int j = 0; j < NCR; ++j) cr[j] = (mine && j < nc) ? Cm[lane * nc + j] : 0.0;
           const double Fi = mine ? Fv[lane] : 0.0, Qi = mine ? Qv[lane] : 0.0, xi = mine ? xl[lane] : 0.0, wi = mine ? wv[lane] : 0.0;
-          const bool is_node = mine && !(a.dmask[uofs + (mine ? lane : 0)] & 2);
+          const bool is_node = mine && !(dml[mine ? lane : 0] & 2);
           const double fnorm = bcast(row_max<NCR>(fabs(Fi)), 0);
           if (lane == 0) s_fnorm = fnorm;
           CH_STAMP(6);
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
               double scale = 1.0;
               if (a.mode == MODE_DC && a.dv_max > 0.0 && cm.nonlinear) {
                 double mm = 0.0;
-                for (int i = lane; i < nc; i += 64) if (!(a.dmask[uofs + i] & 2)) mm = fmax(mm, fabs(A[i * lda + nc]));
+                for (int i = lane; i < nc; i += 64) if (!(dml[i] & 2)) mm = fmax(mm, fabs(A[i * lda + nc]));
                 mm = wave_max(mm);
                 if (mm > a.dv_max) scale = a.dv_max / mm;
               }
@@ -695,9 +700,9 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
         const double xn = xl[i];
         Xc[i] = xn;
         Qc[i] = qn[i];
-        if (a.obs_row) { const int ob = a.unk_obs[uofs + i]; if (ob >= 0) a.obs_row[(long)ob * a.S + s] = xn; }
-        if (a.mode == MODE_TRAN && (a.dmask[uofs + i] & 1)) {
-          const double x0 = X0[i];
+        if (a.obs_row) { const int ob = (dml[i] >> 8) - 1; if (ob >= 0) a.obs_row[(long)ob * a.S + s] = xn; }
+        if (a.mode == MODE_TRAN && (dml[i] & 1)) {
+          const double x0 = x0l[i];
           const double w = 1.0 / (a.reltol * fmax(fabs(x0), fabs(xn)) + a.abstol);
           ++nd;
           double t = (xn - xp[i]) * w; e2k += t * t;
