@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/cedarhip.h"
@@ -297,7 +298,27 @@ struct ch_circuit {
       std::vector<uint16_t> h16(c.mat_src); h16.insert(h16.end(), c.vec_src.begin(), c.vec_src.end());
       if (h16.size() & 1) h16.push_back(0);
       for (size_t i = 0; i < h16.size(); i += 2) blob.push_back((int)((uint32_t)h16[i] | ((uint32_t)h16[i + 1] << 16)));
+      // gather work list of the register-LU variants: structural non-zeros of A/C and all diagonals, then the rows of F/Q;
+      // item = {first source (index into mat_src|vec_src), (sources << 16) | vector flag << 15 | entry}
+      if (((int)blob.size() - m.blob_ofs) & 1) blob.push_back(0);
+      m.wl_ofs = (int)blob.size() - m.blob_ofs;
+      if (c.nc <= 64) {
+        // heaviest items first: when there are more items than lanes, the second pass of a wave holds only the lightest ones
+        std::vector<std::array<int, 3>> items;   // {sources, first source, code}
+        for (int i = 0; i < c.nc; ++i) {
+          const int start = c.vec_ptr[i], cnt = c.vec_ptr[i + 1] - start;
+          items.push_back({cnt, m.n_mat_src + start, (int)(0x8000u | (uint32_t)i)});
+        }
+        for (int e = 0; e < c.nc * c.nc; ++e) {
+          const int start = c.mat_ptr[e], cnt = c.mat_ptr[e + 1] - start;
+          if (cnt == 0 && e / c.nc != e % c.nc) continue;
+          items.push_back({cnt, start, e});
+        }
+        std::stable_sort(items.begin(), items.end(), [](const std::array<int, 3>& x, const std::array<int, 3>& y) { return x[0] > y[0]; });
+        for (const auto& it : items) { blob.push_back(it[1]); blob.push_back((int)(((uint32_t)it[0] << 16) | (uint32_t)it[2])); ++m.n_work; }
+      }
       m.blob_ints = (int)blob.size() - m.blob_ofs;
+      if (std::getenv("CEDARHIP_DEBUG_BLOB")) std::fprintf(stderr, "[blob] class %zu: nc %d ndev %d slots %d mat_src %d vec_src %d work %d blob_ints %d\n", ci, m.nc, m.ndev, m.nslots, m.n_mat_src, m.n_vec_src, m.n_work, m.blob_ints);
       max_slots = std::max(max_slots, m.nslots);
       cms.push_back(m);
     }

@@ -26,7 +26,7 @@ namespace chip {
 
 struct ClassMeta {
   int nc, ndev, nonlinear, nslots;   // nslots: lane slots of the evaluation phase (4 per MOSFET, 1 otherwise)
-  int mat_ptr_ofs, mat_src_ofs, vec_ptr_ofs, vec_src_ofs;  // offsets into the pooled gather arrays
+  int wl_ofs, n_work, spare0, spare1;  // gather work list (register-LU variants): offset inside the blob (ints, even), items
   int n_mat_src, n_vec_src, blob_ofs, blob_ints;            // list lengths; this class's packed list blob (ints)
 };
 
@@ -367,6 +367,8 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
   uint16_t* msrc = (uint16_t*)(slots + cm.nslots);
   uint16_t* vsrc = msrc + cm.n_mat_src;
   int* mcl = mptr + cm.blob_ints;                  // [64] this block's MOS class list (behind the blob)
+  const int2* wl = (const int2*)(mptr + cm.wl_ofs);  // gather work list: {first source, (sources << 16) | vector flag << 15 | entry}
+  const bool use_wl = NC > 0 && nc <= NC;          // register LU: A and C in LDS are never overwritten, so only structural non-zeros are gathered
   __shared__ int s_ctl[4];  // [0] loop control (0 continue, 1 stop), [1] status, [2] iters
   __shared__ double s_fnorm;
   const long sofs = (long)s * a.n_unk + uofs;
@@ -523,6 +525,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       x0l[i] = x0; dml[i] = a.dmask[uofs + i] | (a.obs_row ? (a.unk_obs[uofs + i] + 1) << 8 : 0);
     }
     }
+    if (use_wl) for (int i = tid; i < nc * lda + nc * nc; i += nthr) A[i] = 0.0;   // A and Cm are contiguous
     if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 1; s_ctl[2] = 0; }
     __syncthreads();
     CH_STAMP(0);
@@ -538,6 +541,38 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       __syncthreads();
       CH_STAMP(1);
       // (2) gather (all waves)
+      if (use_wl) {
+        // one work item per structural non-zero of A/C (plus every diagonal) and per row of F/Q: a DFF block has ~55 items,
+        // one pass of one wave, instead of two passes over the 121 matrix entries and a third over the rows
+        for (int w = tid; w < cm.n_work; w += nthr) {
+          const int2 it = wl[w];
+          const int p0 = it.x, pe = p0 + (int)((unsigned)it.y >> 16), e = it.y & 0x7fff;
+          const bool vec = it.y & 0x8000;
+          const int off2 = vec ? SL::QO : SL::CO;
+          double s1 = 0.0, s2 = 0.0;
+          for (int p = p0; p < pe; p += 4) {   // four sources in flight per trip (clamped indices, predicated adds): sequential summation order
+            const int l = pe - 1;
+            const int o0 = msrc[p], o1 = msrc[min(p + 1, l)], o2 = msrc[min(p + 2, l)], o3 = msrc[min(p + 3, l)];
+            const double a0 = st[o0], b0 = st[o0 + off2], a1 = st[o1], b1 = st[o1 + off2], a2 = st[o2], b2 = st[o2 + off2], a3 = st[o3], b3 = st[o3 + off2];
+            s1 += a0; s2 += b0;
+            if (p + 1 < pe) { s1 += a1; s2 += b1; }
+            if (p + 2 < pe) { s1 += a2; s2 += b2; }
+            if (p + 3 < pe) { s1 += a3; s2 += b3; }
+          }
+          if (vec) {
+            if (a.gshunt != 0.0 && !(dml[e] & 2)) s1 += a.gshunt * xl[e];
+            Qv[e] = s2;
+            const double F = s1 + alpha0 * s2 + hq[e];
+            Fv[e] = F;
+            A[e * lda + nc] = -F;
+          } else {
+            const int r = e / nc, col = e - r * nc;
+            if (r == col && a.gshunt != 0.0 && !(dml[r] & 2)) s1 += a.gshunt;  // node rows only
+            A[r * lda + col] = s1 + alpha0 * s2;
+            Cm[e] = s2;
+          }
+        }
+      } else {
       for (int e = tid; e < nc * nc; e += nthr) {
         double g = 0.0, cc = 0.0;
         // four sources in flight per trip (clamped indices, predicated adds): same summation order, a quarter of the LDS round trips
@@ -571,6 +606,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
         const double F = f + alpha0 * q + hq[i];
         Fv[i] = F;
         A[i * lda + nc] = -F;
+      }
       }
       __syncthreads();
       CH_STAMP(2);
