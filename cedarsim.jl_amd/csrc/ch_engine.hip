@@ -277,6 +277,7 @@ struct ch_circuit {
       m.nc = c.nc; m.ndev = c.ndev; m.nonlinear = c.nonlinear ? 1 : 0;
       m.n_mat_src = (int)c.mat_src.size(); m.n_vec_src = (int)c.vec_src.size();
       // one contiguous blob per class, copied verbatim into LDS: mat_ptr | vec_ptr | slots | mat_src | vec_src
+      while (blob.size() & 3) blob.push_back(0);   // class blobs start on 16-byte boundaries (the kernel copies them with 16-byte loads)
       m.blob_ofs = (int)blob.size();
       blob.insert(blob.end(), c.mat_ptr.begin(), c.mat_ptr.end());
       blob.insert(blob.end(), c.vec_ptr.begin(), c.vec_ptr.end());
@@ -317,6 +318,7 @@ struct ch_circuit {
         std::stable_sort(items.begin(), items.end(), [](const std::array<int, 3>& x, const std::array<int, 3>& y) { return x[0] > y[0]; });
         for (const auto& it : items) { blob.push_back(it[1]); blob.push_back((int)(((uint32_t)it[0] << 16) | (uint32_t)it[2])); ++m.n_work; }
       }
+      while ((blob.size() - m.blob_ofs) & 3) blob.push_back(0);
       m.blob_ints = (int)blob.size() - m.blob_ofs;
       if (std::getenv("CEDARHIP_DEBUG_BLOB")) std::fprintf(stderr, "[blob] class %zu: nc %d ndev %d slots %d mat_src %d vec_src %d work %d blob_ints %d\n", ci, m.nc, m.ndev, m.nslots, m.n_mat_src, m.n_vec_src, m.n_work, m.blob_ints);
       max_slots = std::max(max_slots, m.nslots);
@@ -447,7 +449,7 @@ struct ch_circuit {
     }
     n_cls = (int)cls_rep.size();
     const long cols = (long)std::max(1, n_cls) * Smos;
-    std::vector<double> table((size_t)B4I_COUNT * cols, 0.0), col(B4I_COUNT);
+    std::vector<double> table((size_t)B4I_COUNT * cols + 2, 0.0), col(B4I_COUNT);   // + padding: the kernel reads the columns in 16-byte pairs
     for (int c = 0; c < n_cls; ++c) {
       const int hd = A.mos_hdev[cls_rep[c]];
       for (int s = 0; s < Smos; ++s) {
@@ -534,7 +536,7 @@ struct ch_circuit {
 #ifdef CH_STAMPS
     a.stamps = d_stamps.p;
 #endif
-    lds_bytes = (lds_doubles_fixed + A.known.size() + n_dev_src() + (size_t)max_mc * B4I_COUNT) * sizeof(double) + lds_extra_bytes;
+    lds_bytes = (lds_doubles_fixed + A.known.size() + n_dev_src() + (size_t)max_mc * B4L_STRIDE) * sizeof(double) + lds_extra_bytes;
     lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
     path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || max_mc > 64 || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
     if (path == 2) {

@@ -57,6 +57,8 @@ struct Summary {
 
 enum { MODE_DC = 0, MODE_TRAN = 1, MODE_EVAL = 2 };
 constexpr int KV_INLINE = 24;
+// BSIM4 columns in LDS: one class per B4L_STRIDE doubles (even, so a column is a whole number of 16-byte pairs)
+constexpr int B4L_STRIDE = (B4I_COUNT + 1) & ~1;
 
 struct NewtonArgs {
   // ---- circuit structure ----
@@ -176,7 +178,7 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
   const double m = a.dmult[pi];
   if (kind == K_MOS) {
     // parameters come from the block's LDS copy of its classes' packed columns (staged in the prologue)
-    const B4Col P{pl + (size_t)a.dcls_local[d] * B4I_COUNT};
+    const B4Col P{pl + (size_t)a.dcls_local[d] * B4L_STRIDE};
     double o[40];
     b4_device(P, v[0], v[1], v[2], v[3], a.gmin, o);
 #pragma unroll
@@ -360,8 +362,8 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
   double* x0l = pp + nc;                               // accepted state of the previous step (error weights of the epilogue)
   int* dml = (int*)(x0l + nc);                         // unknown flags (bit 0 differential, bit 1 branch row): read once per launch
   double* kvl = x0l + 2 * nc; double* svl = kvl + a.nk;
-  double* pl = svl + a.nsrc;                       // [max_mc][B4I_COUNT] packed BSIM4 columns of this block's classes
-  int* mptr = (int*)(pl + (size_t)a.max_mc * B4I_COUNT);  // start of the class blob copy
+  double* pl = svl + a.nsrc;                       // [max_mc][B4L_STRIDE] packed BSIM4 columns of this block's classes
+  int* mptr = (int*)(pl + (size_t)a.max_mc * B4L_STRIDE);  // start of the class blob copy
   int* vptr = mptr + (nc * nc + 1);
   int* slots = vptr + (nc + 1);
   uint16_t* msrc = (uint16_t*)(slots + cm.nslots);
@@ -382,36 +384,44 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
     // ---- prologue: stage lists / known values / BSIM4 columns in LDS, predictor and history term ----
     // All global loads of one level are issued before any is consumed (batches of 8 per thread), so
     // the prologue costs a few memory latencies instead of one per element.
-    constexpr int PB = 18;  // 8 DFF classes x 137 doubles / 64 lanes = 17.1: one batch of loads in flight
+    constexpr int PB = 18;  // generic path: doubles per thread and batch
+    constexpr int PP = 9;   // fast path: 16-byte pairs per lane (8 DFF classes x 69 pairs / 64 lanes = 8.6)
+    constexpr int NPAIR = B4L_STRIDE / 2;
     const long scol = a.Smos > 1 ? s : 0;
-    const bool fast = nthr == 64 && bm.mc_n <= 8 && cm.blob_ints <= 8 * 64 && bm.mc_n * B4I_COUNT <= PB * 64 && nc <= 64;
+    const bool fast = nthr == 64 && bm.mc_n <= 8 && cm.blob_ints <= 2 * 256 && bm.mc_n * NPAIR <= PP * 64 && nc <= 64;
     if (fast) {
       // One wave, everything fits one batch per lane: ALL global loads of the prologue (class blob, BSIM4 columns of the
       // block's classes, state history) are issued back to back before the first one is consumed — one memory latency
-      // instead of three dependent ones (the class ids come from the BlockMeta registers, not from LDS).
-      const int* src = a.blob + cm.blob_ofs;
-      const int nb = cm.blob_ints, total = bm.mc_n * B4I_COUNT;
-      int bv[8]; double pv[PB]; double x0 = 0.0, xv[7], qv[5];
+      // instead of three dependent ones (the class ids come from the BlockMeta registers, not from LDS).  The cost of this
+      // phase was measured to be per load INSTRUCTION (~280 cycles each with 1024 waves loading at once), not per byte, so
+      // the loads are as wide as the data allows: 16 bytes per lane for the blob and the BSIM4 columns, and history points
+      // the current order does not need are skipped.
+      typedef int i4u __attribute__((ext_vector_type(4), aligned(16)));
+      typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+      const i4u* src = (const i4u*)(a.blob + cm.blob_ofs);    // class blobs start on 16-byte boundaries and are padded to 4 ints
+      const int nq = cm.blob_ints >> 2, npair = bm.mc_n * NPAIR;
+      i4u bv[2]; d2u pv[PP]; double x0 = 0.0, xv[7], qv[5];
       const int nxh = max(a.npred, max(a.nkm1, a.nkp1));   // history points any of the three predictors needs
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = tid + u * 64; bv[u] = src[i < nb ? i : nb - 1]; }
-      if (total > 0) {
-        // Element e = 64u + lane of the concatenated columns: lane 0's class j0 and offset r0 are compile-time constants of
-        // the unrolled loop and a batch of 64 elements straddles at most one class boundary, so the address is one compare
-        // and one select between two wave-uniform bases (no per-lane division / 64-bit multiply chain).
+      for (int u = 0; u < 2; ++u) { const int i = tid + u * 64; bv[u] = src[i < nq ? i : nq - 1]; }
+      if (npair > 0) {
+        // Pair q = 64u + lane of the concatenated columns (69 pairs per class; the last pair of a column reads one double
+        // past it, the table is padded for that): lane 0's class j0 and offset r0 are compile-time constants of the
+        // unrolled loop and a batch of 64 pairs straddles at most one class boundary, so the address is one compare and
+        // one select between two wave-uniform bases (no per-lane division / 64-bit multiply chain).
         int cl = bm.mc[0];
 #pragma unroll
         for (int q = 1; q < 8; ++q) cl = (bm.mc_n - 1 == q) ? bm.mc[q] : cl;
-        const long last = ((long)cl * a.Smos + scol) * (long)B4I_COUNT + (B4I_COUNT - 1);
+        const long last = ((long)cl * a.Smos + scol) * (long)B4I_COUNT + 2 * (NPAIR - 1);
 #pragma unroll
-        for (int u = 0; u < PB; ++u) {
-          const int j0 = (u * 64) / B4I_COUNT, r0 = u * 64 - j0 * B4I_COUNT;
+        for (int u = 0; u < PP; ++u) {
+          const int j0 = (u * 64) / NPAIR, r0 = u * 64 - j0 * NPAIR;
           const int ja = j0 < 8 ? j0 : 7, jb = j0 + 1 < 8 ? j0 + 1 : 7;
-          const long oa = ((long)bm.mc[ja] * a.Smos + scol) * (long)B4I_COUNT + r0;
-          const long ob = ((long)bm.mc[jb] * a.Smos + scol) * (long)B4I_COUNT + (r0 - B4I_COUNT);
-          long idx = (r0 + tid >= B4I_COUNT ? ob : oa) + tid;
-          if (tid + u * 64 >= total) idx = last;   // clamped: branch-free loads
-          pv[u] = a.mosp[idx];
+          const long oa = ((long)bm.mc[ja] * a.Smos + scol) * (long)B4I_COUNT + 2 * r0;
+          const long ob = ((long)bm.mc[jb] * a.Smos + scol) * (long)B4I_COUNT + 2 * (r0 - NPAIR);
+          long idx = (r0 + tid >= NPAIR ? ob : oa) + 2 * tid;
+          if (tid + u * 64 >= npair) idx = last;   // clamped: branch-free loads
+          pv[u] = *(const d2u*)(a.mosp + idx);
         }
       }
       const int iu = tid < nc ? tid : 0;
@@ -419,9 +429,9 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       const int dmr = a.dmask[uofs + iu] | (a.obs_row ? (a.unk_obs[uofs + iu] + 1) << 8 : 0);   // flags | (observable row + 1) << 8
       if (a.mode == MODE_TRAN) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) xv[j] = a.X[(long)a.hist_slot[j < nxh ? j : 0] * a.slot_stride + sofs + iu];
+        for (int j = 0; j < 7; ++j) { xv[j] = 0.0; if (j < nxh) xv[j] = a.X[(long)a.hist_slot[j] * a.slot_stride + sofs + iu]; }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) qv[j] = a.Qh[(long)a.hist_slot[j < a.k ? j : 0] * a.slot_stride + sofs + iu];
+        for (int j = 0; j < 5; ++j) { qv[j] = 0.0; if (j < a.k) qv[j] = a.Qh[(long)a.hist_slot[j] * a.slot_stride + sofs + iu]; }
       }
       if (a.inline_vals) {
         // known-node and source values travel in the kernel arguments: lane i reads entry i of that array with one
@@ -438,10 +448,13 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       }
       // branch-free stores: an out-of-range lane holds the (clamped) last element and rewrites it in place
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = tid + u * 64; mptr[i < nb ? i : nb - 1] = bv[u]; }
-      if (total > 0) {
+      for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 64, q = (i < nq ? i : nq - 1) * 4;
+        mptr[q] = bv[u].x; mptr[q + 1] = bv[u].y; mptr[q + 2] = bv[u].z; mptr[q + 3] = bv[u].w;
+      }
+      if (npair > 0) {
 #pragma unroll
-        for (int u = 0; u < PB; ++u) { const int e = tid + u * 64; pl[e < total ? e : total - 1] = pv[u]; }
+        for (int u = 0; u < PP; ++u) { const int e = tid + u * 64, q = (e < npair ? e : npair - 1) * 2; pl[q] = pv[u].x; pl[q + 1] = pv[u].y; }
       }
       if (tid < nc) {
         double p = x0, h = 0.0;
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
           v[u] = a.mosp[((long)mcl[j] * a.Smos + scol) * (long)B4I_COUNT + i];
         }
 #pragma unroll
-        for (int u = 0; u < PB; ++u) { const int e = base + u * nthr; if (e < total) pl[e] = v[u]; }
+        for (int u = 0; u < PB; ++u) { const int e = base + u * nthr; if (e < total) { const int j = e / B4I_COUNT; pl[e + j * (B4L_STRIDE - B4I_COUNT)] = v[u]; } }
       }
     }
     for (int i = tid; i < nc; i += nthr) {
