@@ -626,3 +626,50 @@ def test_random_circuits_dc_and_residual_parity_with_oracle(E, O):
             vo = vo if vo.ndim == 2 else vo[:, :, 0]
             assert rce == 0 and rco == 0, (trial, rce, rco)
             assert np.abs(ve[:, :, 0] - vo).max() < 1e-4 * max(1.0, np.abs(vo).max()), (trial, np.abs(ve[:, :, 0] - vo).max())
+
+
+def _dense_mesh(n_nodes, rng, n_cg=None, n_mos=None):
+    """Every pair of nodes joined by a resistor, every node with a capacitor to ground, a handful of MOSFETs and a PWL
+    supply behind a resistor: ONE block of n_nodes unknowns whose gather lists are as long as the block size allows."""
+    from cedarsim_jl_amd.workloads import gf180_models
+    c = Circuit(gmin=1e-12)
+    m = gf180_models()
+    mn, mp = c.add_model(*m["nfet_06v0"]), c.add_model(*m["pfet_06v0"])
+    names = ["n%d" % i for i in range(1, n_nodes + 1)]
+    c.V("vdd", "vdd", 0, dc=5.0, tran=PWL([0.0, 5.0, 2e-7, 2.0, 5e-7, 2.0, 6e-7, 5.0, 1.0, 5.0]))
+    for i, a in enumerate(names):
+        c.R("rs%d" % i, "vdd" if i % 3 == 0 else 0, a, float(10 ** rng.uniform(3, 4)))
+        if n_cg is None or i < n_cg:
+            c.C("cg%d" % i, a, 0, float(10 ** rng.uniform(-13, -12)))
+        for j in range(i + 1, n_nodes):
+            c.R("r%d_%d" % (i, j), a, names[j], float(10 ** rng.uniform(3, 5)))
+    for k in range(min(6, n_nodes // 2) if n_mos is None else n_mos):
+        d, g, s = names[(3 * k) % n_nodes], names[(3 * k + 1) % n_nodes], names[(3 * k + 2) % n_nodes]
+        if k % 2 == 0:
+            c.M("mn%d" % k, d, g, s, 0, mn, 1e-6, 6e-7)
+        else:
+            c.M("mp%d" % k, d, g, s, "vdd", mp, 1e-6, 6e-7)
+    c.observe_all_nodes()
+    return c
+
+
+def test_dense_blocks_of_every_kernel_variant_match_oracle(E, O):
+    """One fully coupled block per size: 7 unknowns (register LU <8>, single-batch prologue), 10 with exactly 64 devices
+    (register LU <12>; class blob between 512 and 768 ints: third 16-byte blob load of the single-batch prologue), 12, 16
+    and 28 (register LU <12>/<16>/<32>, several waves per block, gather work list in several passes, three-level prologue)
+    and 40 (LDS LU, full gather).  DC rtol 1e-6, transient 1e-4 against the oracle."""
+    rng = np.random.default_rng(7)
+    sv = np.array([1e-7, 2e-7, 3.5e-7, 5.5e-7, 6e-7, 1e-6])
+    for n, kw in ((7, {}), (10, dict(n_cg=5, n_mos=4)), (12, {}), (16, {}), (28, {}), (40, {})):
+        c = _dense_mesh(n, rng, **kw)
+        rc_o, x_o, _ = O(c).dc(dc_opts(abstol=1e-12))
+        rc, x, status, st = E(c).dc(dc_opts(abstol=1e-12))
+        assert rc_o == 0 and rc == 0, (n, rc_o, rc)
+        known = ~np.isnan(x[0])
+        assert np.allclose(x[0][known], x_o[known], rtol=1e-6, atol=1e-9), (n, np.abs(x[0][known] - x_o[known]).max())
+        opts = lambda: tran_opts(abstol=1e-9, reltol=1e-6, saveat=sv, dc=dc_opts(abstol=1e-12, tran_mode=1))  # noqa: E731
+        rce, te, ve, _, _ = E(c).tran(0.0, 1e-6, opts())
+        rco, to, vo, _, _ = O(c).tran(0.0, 1e-6, opts())
+        vo = vo if vo.ndim == 2 else vo[:, :, 0]
+        assert rce == 0 and rco == 0, (n, rce, rco)
+        assert np.abs(ve[:, :, 0] - vo).max() < 1e-4 * max(1.0, np.abs(vo).max()), (n, np.abs(ve[:, :, 0] - vo).max())
