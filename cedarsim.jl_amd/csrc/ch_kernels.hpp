@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
     constexpr int PP = 9;   // fast path: 16-byte pairs per lane (8 DFF classes x 69 pairs / 64 lanes = 8.6)
     constexpr int NPAIR = B4L_STRIDE / 2;
     const long scol = a.Smos > 1 ? s : 0;
-    const bool fast = nthr == 64 && bm.mc_n <= 8 && cm.blob_ints <= 3 * 256 && bm.mc_n * NPAIR <= PP * 64 && nc <= 64;
+    const bool fast = nthr == 64 && bm.mc_n <= 8 && cm.blob_ints <= 2 * 256 && bm.mc_n * NPAIR <= PP * 64 && nc <= 64;
     if (fast) {
       // One wave, everything fits one batch per lane: ALL global loads of the prologue (class blob, BSIM4 columns of the
       // block's classes, state history) are issued back to back before the first one is consumed — one memory latency
@@ -400,10 +400,10 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
       const i4u* src = (const i4u*)(a.blob + cm.blob_ofs);    // class blobs start on 16-byte boundaries and are padded to 4 ints
       const int nq = cm.blob_ints >> 2, npair = bm.mc_n * NPAIR;
-      i4u bv[3]; d2u pv[PP]; double x0 = 0.0, xv[7], qv[5];
+      i4u bv[2]; d2u pv[PP]; double x0 = 0.0, xv[7], qv[5];
       const int nxh = max(a.npred, max(a.nkm1, a.nkp1));   // history points any of the three predictors needs
 #pragma unroll
-      for (int u = 0; u < 3; ++u) { const int i = tid + u * 64; if (u < 2 || nq > 128) bv[u] = src[i < nq ? i : nq - 1]; }   // third load only for blobs above 512 ints
+      for (int u = 0; u < 2; ++u) { const int i = tid + u * 64; bv[u] = src[i < nq ? i : nq - 1]; }
       if (npair > 0) {
         // Pair q = 64u + lane of the concatenated columns (69 pairs per class; the last pair of a column reads one double
         // past it, the table is padded for that): lane 0's class j0 and offset r0 are compile-time constants of the
@@ -448,9 +448,9 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
       }
       // branch-free stores: an out-of-range lane holds the (clamped) last element and rewrites it in place
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const int i = tid + u * 64, q = (i < nq ? i : nq - 1) * 4;
-        if (u < 2 || nq > 128) { mptr[q] = bv[u].x; mptr[q + 1] = bv[u].y; mptr[q + 2] = bv[u].z; mptr[q + 3] = bv[u].w; }
+        mptr[q] = bv[u].x; mptr[q + 1] = bv[u].y; mptr[q + 2] = bv[u].z; mptr[q + 3] = bv[u].w;
       }
       if (npair > 0) {
 #pragma unroll

@@ -655,9 +655,9 @@ def _dense_mesh(n_nodes, rng, n_cg=None, n_mos=None):
 
 def test_dense_blocks_of_every_kernel_variant_match_oracle(E, O):
     """One fully coupled block per size: 7 unknowns (register LU <8>, single-batch prologue), 10 with exactly 64 devices
-    (register LU <12>; class blob between 512 and 768 ints: third 16-byte blob load of the single-batch prologue), 12, 16
-    and 28 (register LU <12>/<16>/<32>, several waves per block, gather work list in several passes, three-level prologue)
-    and 40 (LDS LU, full gather).  DC rtol 1e-6, transient 1e-4 against the oracle."""
+    (register LU <12>, one wave, class blob just above the 512 ints of the single-batch prologue -> three-level prologue),
+    12, 16 and 28 (register LU <12>/<16>/<32>, several waves per block, gather work list in several passes) and 40 (LDS LU,
+    full gather).  DC rtol 1e-6, transient 1e-4 against the oracle."""
     rng = np.random.default_rng(7)
     sv = np.array([1e-7, 2e-7, 3.5e-7, 5.5e-7, 6e-7, 1e-6])
     for n, kw in ((7, {}), (10, dict(n_cg=5, n_mos=4)), (12, {}), (16, {}), (28, {}), (40, {})):
