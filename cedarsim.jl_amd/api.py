@@ -308,12 +308,20 @@ class CircuitSweep:
     builder: a parsed netlist (`.build(**params)`) or a callable `f(**params) -> Circuit`.
     Iterating yields one parameter dict per point (`s.params` in the reference)."""
 
-    def __init__(self, builder, sweep, rank=0, world=1):
+    def __init__(self, builder, sweep, rank=0, world=1, groups="auto"):
         self.builder = builder
         self.sweep = sweepify(sweep)
         self.points = [{k: v for k, v in p if v is not None} for p in self.sweep]
         self.shape = self.sweep.shape
         self.rank, self.world = rank, world
+        # groups > 1: this rank's points are split into that many contiguous groups, each a batched solve of its own with its
+        # own stream and host stepper (one thread each).  A step attempt of one group costs ~36 us of kernel plus ~16 us of
+        # host round trip during which the GPU would idle; a second group's kernel fills that gap (profiles/r01_notes.md),
+        # and every group steps with the time steps ITS samples need.
+        # Measured on one MI355X (scripts/sweep_groups.py, Monte-Carlo batch of one DFF): 8192 samples 0.46 s in one group,
+        # 0.38 s in two, 0.35 s in four; no gain at 1024 samples (one launch does not fill the GPU there).  "auto": 4 groups
+        # from 4096 points per rank, 2 from 2048, else 1.
+        self.groups = groups if groups == "auto" else max(1, int(groups))
         self._build = builder.build if hasattr(builder, "build") else builder
 
     def __iter__(self):
@@ -376,6 +384,24 @@ class CircuitSweep:
         lo, hi = shard_range(len(self.points), self.rank, self.world)
         if hi <= lo:
             return []
+        n = hi - lo
+        G = (4 if n >= 4096 else 2 if n >= 2048 else 1) if self.groups == "auto" else min(self.groups, n)
+        if G <= 1:
+            return self._run_range(kind, kw, ctx, lo, hi)
+        from concurrent.futures import ThreadPoolExecutor
+        from .engine import Context, default_context
+        first = ctx if ctx is not None else default_context()
+        ctxs = [first] + [Context(first.device_id) for _ in range(G - 1)]
+
+        def work(g):
+            a, b = shard_range(hi - lo, g, G)
+            return self._run_range(kind, dict(kw), ctxs[g], lo + a, lo + b)
+
+        with ThreadPoolExecutor(G) as ex:
+            parts = list(ex.map(work, range(G)))
+        return [sol for part in parts for sol in part]
+
+    def _run_range(self, kind, kw, ctx, lo, hi):
         base, slot_ids, vals = self._batch(lo, hi)
         ckt = _prepare(base, None)
         eng = EngineCircuit(ckt, ctx)

@@ -104,6 +104,7 @@ class Context:
         self.h = self.L.ch_create(device_id, buf, 512)
         if not self.h:
             raise RuntimeError("ch_create failed: %s" % buf.value.decode())
+        self.device_id = device_id
 
     def last_error(self):
         return self.L.ch_last_error(self.h).decode()
