@@ -301,6 +301,11 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     CompClass cl;
     cl.nc = A.comp_nc[c]; cl.ndev = A.comp_ndev[c];
     const int stride = A.stride(), gofs = A.g_ofs(), gld = A.g_ld();
+    if (cl.nc > 64) {   // such a circuit takes the sparse path (its own CSR assembly): no dense gather lists, no size limit here
+      for (int i = 0; i < cl.ndev; ++i) { const int kd = A.edev[A.comp_dofs[c] + i].kind; if (kd == K_MOS || kd == K_VA) cl.nonlinear = true; }
+      A.classes.push_back(std::move(cl));
+      continue;
+    }
     if ((long)cl.ndev * stride > 65535) { A.err = "component too large for 16-bit staging offsets"; return CH_ERR_UNSUPPORTED; }
     std::vector<std::vector<uint16_t>> ml((size_t)cl.nc * cl.nc), vl(cl.nc);
     for (int i = 0; i < cl.ndev; ++i) {

@@ -667,7 +667,7 @@ struct ch_circuit {
     return CH_OK;
   }
   // Small-signal analyses see the circuit as dense blocks: the Jacobian blocks of the fused path, or — on the sparse path —
-  // the whole system as one block per sample (up to 96 unknowns: 2·n·(n+1) doubles of LDS for the complex LU)
+  // the whole system as one block per sample (up to 96 unknowns the complex LU runs in LDS, above that in a global workspace)
   DevBuf<BlockMeta> d_bmeta_all;
   int ac_ncomp() const { return path == 2 ? 1 : A.n_comp; }
   int ac_ds() const { return path == 2 ? A.n_unk : A.max_nc; }
@@ -1430,7 +1430,7 @@ int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double
 static int ac_linearise(ch_circuit* c, const ch_dc_opts* o, ch_stats* st, bool want_b) {
   int rc = c->finalize_params();
   if (rc != CH_OK) return rc;
-  if (c->path == 2 && c->A.n_unk > 96) { c->set_err("AC / noise analysis: the coupled system has more than 96 unknowns (the complex LU works in one CU's LDS)"); return CH_ERR_UNSUPPORTED; }
+  if (c->path == 2 && c->A.n_unk > 4096) { c->set_err("AC / noise analysis: the coupled system has more than 4096 unknowns (dense complex LU)"); return CH_ERR_UNSUPPORTED; }
   g_arena = &c->arena;
   rc = c->dc_solve(*o, 0, nullptr, st);
   if (rc != CH_OK) return rc;
@@ -1465,6 +1465,33 @@ static int ac_linearise(ch_circuit* c, const ch_dc_opts* o, ch_stats* st, bool w
   return CH_OK;
 }
 
+// (G + jwC) solves of one analysis: `ny` systems per frequency.  Up to 96 unknowns the complex LU of a system runs in one
+// wavefront with its matrices in LDS; larger coupled systems (sparse path) take the 256-thread variant with a global
+// workspace, a chunk of frequencies per launch so that the workspace stays below 1 GiB.
+static int launch_ac(ch_circuit* c, AcArgs& a, int n_freq, int ny, int ds) {
+  const size_t per = (size_t)2 * ds * (ds + 1);
+  if (ds <= 96) {
+    const size_t lds = per * sizeof(double);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ac_block_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    a.work = nullptr; a.f0 = 0;
+    hipLaunchKernelGGL(ac_block_kernel<64>, dim3(n_freq, ny), dim3(64), lds, c->ctx->stream, a);
+    return hipGetLastError() == hipSuccess ? CH_OK : CH_ERR_DEVICE;
+  }
+  const size_t cap = (size_t)1 << 27;   // doubles
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_freq, cap / (per * (size_t)ny)));
+  double* work = nullptr;
+  if (hipMalloc((void**)&work, (size_t)chunk * ny * per * sizeof(double)) != hipSuccess) { c->set_err("AC / noise analysis: out of device memory for the dense complex LU workspace"); return CH_ERR_DEVICE; }
+  int rc = CH_OK;
+  for (int f0 = 0; f0 < n_freq && rc == CH_OK; f0 += chunk) {
+    a.work = work; a.f0 = f0;
+    hipLaunchKernelGGL(ac_block_kernel<256>, dim3(std::min(chunk, n_freq - f0), ny), dim3(256), 0, c->ctx->stream, a);
+    if (hipGetLastError() != hipSuccess) rc = CH_ERR_DEVICE;
+  }
+  if (hipStreamSynchronize(c->ctx->stream) != hipSuccess) rc = CH_ERR_DEVICE;
+  (void)hipFree(work);
+  return rc;
+}
+
 static int upload_omega(ch_circuit* c, int n_freq, const double* freqs_hz) {
   std::vector<double> w(n_freq);
   for (int i = 0; i < n_freq; ++i) { if (!(freqs_hz[i] >= 0.0) || !std::isfinite(freqs_hz[i])) { c->set_err("frequencies must be finite and non-negative"); return CH_ERR_INVALID; } w[i] = 6.283185307179586 * freqs_hz[i]; }
@@ -1494,9 +1521,8 @@ int ch_ac(ch_circuit* c, const ch_dc_opts* o, int32_t n_freq, const double* freq
   a.bmeta = c->ac_bmeta(); a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = c->d_dumpF.p; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = c->ac_ncomp();
   if (!a.bmeta) return CH_ERR_DEVICE;
   a.omega = c->d_omega.p; a.x_out = c->d_xac.p; a.noise = 0; a.fail = c->d_acfail.p;
-  const size_t lds = (size_t)2 * ds * (ds + 1) * sizeof(double);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ac_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(ac_block_kernel, dim3(n_freq, nblk), dim3(64), lds, c->ctx->stream, a);
+  rc = launch_ac(c, a, n_freq, nblk, ds);
+  if (rc != CH_OK) return rc;
   std::vector<double> xs(nx);
   int fail = 0;
   if (hipMemcpyAsync(xs.data(), c->d_xac.p, nx * sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
@@ -1572,9 +1598,7 @@ int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_i
   a.omega = c->d_omega.p; a.noise = 1; a.comp_out = comp; a.row_out = u_out - uofs; a.n_noise = n_tab;
   a.noise_a = c->d_noise_a.p; a.noise_b = c->d_noise_b.p; a.noise_pwr = c->d_noise_pwr.p; a.noise_exp = c->d_noise_exp.p;
   a.psd_out = c->d_psd.p; a.fail = c->d_acfail.p;
-  const size_t lds = (size_t)2 * ds * (ds + 1) * sizeof(double);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ac_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(ac_block_kernel, dim3(n_freq, S), dim3(64), lds, c->ctx->stream, a);
+  { const int rc_l = launch_ac(c, a, n_freq, S, ds); if (rc_l != CH_OK) return rc_l; }
   int fail = 0;
   if (hipMemcpyAsync(psd_out, c->d_psd.p, (size_t)S * n_freq * sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
       hipMemcpyAsync(&fail, c->d_acfail.p, sizeof(int), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||

@@ -886,7 +886,8 @@ __global__ __launch_bounds__(64) void mos_eval_quad_kernel(const double* mosp, l
 // (src/ac.jl:75-102, 267-284) and, transposed with a unit right-hand side, the adjoint solve behind
 // noise! / PSD (src/ac.jl:136-163, 286-305).  G, C and b come from MODE_EVAL dumps of the Newton kernel
 // at the DC operating point, so the device arithmetic is the one the transient uses.
-// One wavefront per (frequency, block): complex dense LU with partial pivoting in LDS.
+// One wavefront per (frequency, block): complex dense LU with partial pivoting in LDS; one 256-thread workgroup with a global
+// workspace for coupled systems that do not fit LDS.
 struct AcArgs {
   const BlockMeta* bmeta;
   const double* G; const double* C; const double* b;  // dumps: [nblk][ds][ds], [nblk][ds]
@@ -900,79 +901,96 @@ struct AcArgs {
   const double* noise_pwr; const double* noise_exp;   // [S][n_noise] power at the operating point, flicker exponent (0 = white)
   double* psd_out;                                    // [S][n_freq]
   int* fail;                                          // set to 1 when a factorisation breaks down
+  double* work; int f0;                               // global workspace [systems of this launch][2*nc*(nc+1)] (T = 256 variant); first frequency of this launch
 };
 
-__global__ __launch_bounds__(64) void ac_block_kernel(const AcArgs a) {
+// T = 64: one wavefront, matrices in LDS (blocks of the fused path, coupled systems up to 96 unknowns).
+// T = 256: one workgroup, matrices in a global workspace (a.work; larger coupled systems of the sparse path) — same algorithm,
+// workgroup barriers instead of wave-local fences.
+template <int T>
+__global__ __launch_bounds__(T) void ac_block_kernel(const AcArgs a) {
   extern __shared__ double lds[];
-  const int lane = threadIdx.x, f = blockIdx.x;
+  constexpr bool MULTI = T > 64;
+  __shared__ double s_best[4]; __shared__ int s_bi[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, f = a.f0 + blockIdx.x;
   const int blk = a.noise ? a.comp_out * a.S + (int)blockIdx.y : (int)blockIdx.y;
   const int c = blk / a.S, s = blk - c * a.S;
   const BlockMeta bm = a.bmeta[c];
   const int nc = bm.cm.nc, lda = nc + 1;
-  double* Ar = lds; double* Ai = Ar + (size_t)nc * lda;
+  double* Ar = a.work ? a.work + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * (size_t)nc * lda : lds;
+  double* Ai = Ar + (size_t)nc * lda;
+  auto fence = [&]() { if (MULTI) __syncthreads(); else wave_fence(); };
   const double w = a.omega[f];
   const double* G = a.G + (long)blk * a.ds * a.ds; const double* Cg = a.C + (long)blk * a.ds * a.ds;
-  for (int e = lane; e < nc * nc; e += 64) {
+  for (int e = tid; e < nc * nc; e += T) {
     const int r = e / nc, col = e - r * nc;
     const int src = a.noise ? col * nc + r : e;  // adjoint: transpose
     Ar[r * lda + col] = G[src]; Ai[r * lda + col] = w * Cg[src];
   }
-  for (int i = lane; i < nc; i += 64) { Ar[i * lda + nc] = a.noise ? (i == a.row_out ? 1.0 : 0.0) : a.b[(long)blk * a.ds + i]; Ai[i * lda + nc] = 0.0; }
-  wave_fence();
+  for (int i = tid; i < nc; i += T) { Ar[i * lda + nc] = a.noise ? (i == a.row_out ? 1.0 : 0.0) : a.b[(long)blk * a.ds + i]; Ai[i * lda + nc] = 0.0; }
+  fence();
   bool ok = true;
   for (int k = 0; k < nc && ok; ++k) {
     double best = -1.0; int bi = k;
-    for (int i = k + lane; i < nc; i += 64) { const double v = fabs(Ar[i * lda + k]) + fabs(Ai[i * lda + k]); if (v > best) { best = v; bi = i; } }
+    for (int i = k + tid; i < nc; i += T) { const double v = fabs(Ar[i * lda + k]) + fabs(Ai[i * lda + k]); if (v > best) { best = v; bi = i; } }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
+    if (MULTI) {
+      if (lane == 0) { s_best[wv] = best; s_bi[wv] = bi; }
+      __syncthreads();
+      best = s_best[0]; bi = s_bi[0];
+#pragma unroll
+      for (int q = 1; q < T / 64; ++q) { const double ob = s_best[q]; const int oi = s_bi[q]; if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; } }
+      __syncthreads();   // s_best / s_bi are rewritten in the next step
+    }
     if (!(best > 0.0) || !(best < 1e300)) { ok = false; break; }
     if (bi != k) {
-      for (int j = lane; j <= nc; j += 64) {
+      for (int j = tid; j <= nc; j += T) {
         double t = Ar[k * lda + j]; Ar[k * lda + j] = Ar[bi * lda + j]; Ar[bi * lda + j] = t;
         t = Ai[k * lda + j]; Ai[k * lda + j] = Ai[bi * lda + j]; Ai[bi * lda + j] = t;
       }
-      wave_fence();
+      fence();
     }
     const double pr = Ar[k * lda + k], pi = Ai[k * lda + k];
     const double den = 1.0 / (pr * pr + pi * pi), ir = pr * den, ii = -pi * den;  // 1/pivot
-    for (int i = k + 1 + lane; i < nc; i += 64) {
+    for (int i = k + 1 + tid; i < nc; i += T) {
       const double lr = Ar[i * lda + k], li = Ai[i * lda + k];
       Ar[i * lda + k] = lr * ir - li * ii; Ai[i * lda + k] = lr * ii + li * ir;
     }
-    wave_fence();
+    fence();
     const int rem = nc - k - 1, wd = rem + 1;
-    for (int e = lane; e < rem * wd; e += 64) {
+    for (int e = tid; e < rem * wd; e += T) {
       const int i = k + 1 + e / wd, j = k + 1 + e % wd;
       const double lr = Ar[i * lda + k], li = Ai[i * lda + k], ur = Ar[k * lda + j], ui = Ai[k * lda + j];
       Ar[i * lda + j] -= lr * ur - li * ui; Ai[i * lda + j] -= lr * ui + li * ur;
     }
-    wave_fence();
+    fence();
   }
   if (ok) {
     for (int k = nc - 1; k >= 0; --k) {
       const double pr = Ar[k * lda + k], pi = Ai[k * lda + k], br = Ar[k * lda + nc], bi_ = Ai[k * lda + nc];
       const double den = 1.0 / (pr * pr + pi * pi);
       const double xr = (br * pr + bi_ * pi) * den, xi = (bi_ * pr - br * pi) * den;
-      wave_fence();
-      if (lane == 0) { Ar[k * lda + nc] = xr; Ai[k * lda + nc] = xi; }
-      for (int i = lane; i < k; i += 64) {
+      fence();
+      if (tid == 0) { Ar[k * lda + nc] = xr; Ai[k * lda + nc] = xi; }
+      for (int i = tid; i < k; i += T) {
         const double ur = Ar[i * lda + k], ui = Ai[i * lda + k];
         Ar[i * lda + nc] -= ur * xr - ui * xi; Ai[i * lda + nc] -= ur * xi + ui * xr;
       }
-      wave_fence();
+      fence();
     }
-  } else if (lane == 0) *a.fail = 1;
+  } else if (tid == 0) *a.fail = 1;
   if (!a.noise) {
     double* xo = a.x_out + (((long)s * a.n_freq + f) * a.n_unk + bm.uofs) * 2;
-    for (int i = lane; i < nc; i += 64) { xo[2 * i] = ok ? Ar[i * lda + nc] : CH_NAN; xo[2 * i + 1] = ok ? Ai[i * lda + nc] : CH_NAN; }
+    for (int i = tid; i < nc; i += T) { xo[2 * i] = ok ? Ar[i * lda + nc] : CH_NAN; xo[2 * i + 1] = ok ? Ai[i * lda + nc] : CH_NAN; }
   } else {
     // output PSD = Σ_k |y_a - y_b|² · pwr_k / f^exp_k  (PSD(dss, ωs, pwr, exp), src/ac.jl:286-298)
     const double fhz = w * 0.15915494309189535;
     double acc = 0.0;
-    for (int k = lane; k < a.n_noise; k += 64) {
+    for (int k = tid; k < a.n_noise; k += T) {
       const long e = (long)s * a.n_noise + k;
       const double pw = a.noise_pwr[e];
       if (pw == 0.0) continue;
@@ -983,7 +1001,15 @@ __global__ __launch_bounds__(64) void ac_block_kernel(const AcArgs a) {
       acc += (yr * yr + yi * yi) * (ex == 0.0 ? pw : pw / pow(fhz, ex));
     }
     acc = wave_sum(acc);
-    if (lane == 0) a.psd_out[(long)s * a.n_freq + f] = ok ? acc : CH_NAN;
+    if (MULTI) {
+      __syncthreads();
+      if (lane == 0) s_best[wv] = acc;
+      __syncthreads();
+      acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < T / 64; ++q) acc += s_best[q];
+    }
+    if (tid == 0) a.psd_out[(long)s * a.n_freq + f] = ok ? acc : CH_NAN;
   }
 }
 

@@ -48,6 +48,7 @@ int main() {
     if (tot != A.n_unk) { printf("component sizes do not add up\n"); return 1; }
     for (const EDev& e : A.edev) for (int k = 0; k < NTERM; ++k) if (e.term[k] >= A.n_unk || e.term[k] < -(int)A.known.size()) { printf("terminal out of range\n"); return 1; }
     for (const CompClass& c : A.classes) {
+      if (c.nc > 64) { if (!c.mat_ptr.empty() || !c.vec_ptr.empty()) { printf("sparse-path class with gather lists\n"); return 1; } continue; }
       if ((int)c.mat_ptr.size() != c.nc * c.nc + 1 || (int)c.vec_ptr.size() != c.nc + 1) { printf("list sizes\n"); return 1; }
       for (uint16_t o : c.mat_src) if (o >= c.ndev * A.stride()) { printf("mat offset out of range\n"); return 1; }
       for (uint16_t o : c.vec_src) if (o >= c.ndev * A.stride()) { printf("vec offset out of range\n"); return 1; }

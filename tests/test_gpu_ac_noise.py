@@ -224,3 +224,46 @@ def test_ac_and_noise_on_the_sparse_path_match_oracle(E, O):
     rc_o, po = O(c).noise(c._n("o3") - 1, f, dc_opts(abstol=1e-11))
     assert rc == 0 and rc_o == 0 and np.all(pe[0] > 0)
     assert np.allclose(pe[0], po, rtol=1e-6)
+
+
+def _ac_ladder(n):
+    c = Circuit()
+    c.V("vin", "n0", 0, dc=0.0, ac=1.0)
+    for i in range(n):
+        c.R("r%d" % i, "n%d" % i, "n%d" % (i + 1), 1e3)
+        c.C("c%d" % i, "n%d" % (i + 1), 0, 1e-12)
+    c.observe_node("n%d" % n)
+    return c
+
+
+def test_ac_and_noise_of_a_large_coupled_system_match_oracle(E, O):
+    """More than 96 coupled unknowns: the complex LU leaves LDS and runs as one 256-thread workgroup per (frequency, sample)
+    on a global workspace.  A 300-section RC ladder (sparse path), two samples with different values of one resistor,
+    against the oracle's host LU; the thermal noise of its 300 resistors at the far end likewise.  A system above 4096
+    unknowns is declined."""
+    n = 300
+    c = _ac_ladder(n)
+    slot = c.slot("r7")
+    e = E(c, small_signal=True)
+    e.set_samples(2)
+    e.set_params([slot], [[1e3, 2.5e3]])
+    freqs = np.logspace(2, 5.5, 17)
+    rc, x, st = e.ac(freqs, dc_opts(abstol=1e-12))
+    assert rc == 0, e.ctx.last_error()
+    assert e.info()["path"] == 2 and e.info()["n_unknowns"] > 96
+    out = c._n("n%d" % n)
+    rce, pe, _ = e.noise(0, out, freqs, dc_opts(abstol=1e-12))
+    assert rce == 0, e.ctx.last_error()
+    for s_, r7 in enumerate((1e3, 2.5e3)):
+        o = O(c)
+        o.set_param(slot, r7)
+        rco, xo = o.ac(freqs, dc_opts(abstol=1e-12))
+        assert rco == 0
+        nodes = [c._n("n%d" % k) - 1 for k in (1, 7, 8, n // 2, n)]
+        assert np.abs(x[s_][:, nodes] - xo[:, nodes]).max() <= 1e-6 * np.abs(xo[:, nodes]).max()
+        rcn, psd = o.noise(out - 1, freqs, dc_opts(abstol=1e-12))
+        assert rcn == 0 and np.all(psd > 0)
+        assert np.allclose(pe[s_], psd, rtol=1e-6, atol=0.0)
+    big = E(_ac_ladder(4200), small_signal=True)
+    rc, _, _ = big.ac(freqs[:2], dc_opts(abstol=1e-12))
+    assert rc != 0 and "4096" in big.ctx.last_error()

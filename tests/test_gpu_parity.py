@@ -697,3 +697,31 @@ def test_sweep_in_concurrent_groups_matches_single_batch():
         out[g] = np.array([s["q"] for s in sols])
         assert np.max(np.abs(out[g] - np.array(DFF_CHECK_Q)[None, :])) < 1e-3
     assert np.max(np.abs(out[1] - out[2])) < 2e-3
+
+
+def test_large_coupled_component_takes_the_sparse_path():
+    """One coupled component of 3000 unknowns and 6001 devices (more than the 16-bit staging offsets of the fused kernel's
+    gather lists can address — such a circuit never builds them): loaded resistor ladder with a capacitor per node, DC
+    against the closed form of the divider, then the step response must rise monotonically to that DC solution."""
+    from cedarsim_jl_amd import tran as tran_api
+    n, R, RL = 3000, 10.0, 2.0e4
+    c = Circuit()
+    def build(vdc):
+        c = Circuit()
+        c.V("vin", "n0", 0, dc=vdc, tran=PWL([0.0, 0.0, 1e-9, 1.0, 1.0, 1.0]))
+        for i in range(n):
+            c.R("r%d" % i, "n%d" % i, "n%d" % (i + 1), R)
+            c.C("c%d" % i, "n%d" % (i + 1), 0, 1e-15)
+        c.R("rl", "n%d" % n, 0, RL)
+        for k in (1, n // 2, n):
+            c.observe_node("n%d" % k)
+        return c
+
+    sol = dc(build(1.0), abstol=1e-12)
+    itot = 1.0 / (n * R + RL)
+    for k in (1, n // 2, n):
+        assert approx(sol["n%d" % k][0], 1.0 - k * R * itot, 1e-6), k
+    s2 = tran_api(build(0.0), tspan=(0.0, 8e-7), abstol=1e-9, reltol=1e-6)   # starts discharged; RC of the line ~ 0.1 us
+    assert s2.retcode == "Success"
+    v = s2["n%d" % n]
+    assert abs(v[0]) < 1e-9 and np.all(np.diff(v) > -1e-7) and approx(v[-1], 1.0 - n * R * itot, 1e-4)
