@@ -271,8 +271,8 @@ int32_t ch_bsim4_param_ignored(const char* name); /* 1 if accepted-and-ignored *
  * C·(jωE − A)⁻¹·B per frequency.  Here: G = ∂i/∂x and C = ∂q/∂x from the same device kernels at the DC
  * point, and one batched complex LU (G + jωC)·x = b per (block, sample, frequency) on the GPU.
  * freqs_hz[n_freq]; x_ac_out[n_samples][n_freq][n_mna][2] (re, im) in MNA order, like ch_dc's x_out
- * (eliminated branch currents are NaN; nodes tied to ground through non-AC sources are 0).  Jacobian blocks must fit one CU;
- * a circuit on the sparse path is taken as one block and may have up to 96 unknowns. ---- */
+ * (eliminated branch currents are NaN; nodes tied to ground through non-AC sources are 0).  A circuit on the sparse path is
+ * taken as one dense block per sample and may have up to 4096 unknowns (CH_ERR_UNSUPPORTED above that). ---- */
 int ch_ac(ch_circuit*, const ch_dc_opts*, int32_t n_freq, const double* freqs_hz, double* x_ac_out, ch_stats* stats);
 
 /* ---- output-noise PSD.  Replaces: noise!(circ) + PSD(noise, sym, ωs) (src/ac.jl:136-163, 178-186, 286-305).
