@@ -21,9 +21,9 @@ SRC_DC, SRC_PWL, SRC_PULSE, SRC_SIN = 0, 1, 2, 3
 SRC_NPAR = 8
 SLOT_DEV_PAR, SLOT_MODEL_PAR, SLOT_SRC_DC, SLOT_SRC_PAR, SLOT_TEMP, SLOT_GMIN, SLOT_DEV_MULT, SLOT_VA_PAR = 1, 2, 3, 4, 5, 6, 7, 8
 
-OK, ERR_INVALID, ERR_SINGULAR, ERR_MAXITERS, ERR_DTMIN, ERR_DEVICE, ERR_UNSUPPORTED, ERR_MAXSTEPS = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_INVALID, ERR_SINGULAR, ERR_MAXITERS, ERR_DTMIN, ERR_DEVICE, ERR_UNSUPPORTED, ERR_MAXSTEPS, ERR_NOMEM, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 RETCODES = {0: "Success", -1: "Invalid", -2: "Singular", -3: "InitialFailure", -4: "DtLessThanMin",
-            -5: "DeviceError", -6: "Unsupported", -7: "MaxIters"}
+            -5: "DeviceError", -6: "Unsupported", -7: "MaxIters", -8: "OutOfMemory", -9: "InternalError"}
 
 _pi32 = C.POINTER(C.c_int32)
 _pf64 = C.POINTER(C.c_double)

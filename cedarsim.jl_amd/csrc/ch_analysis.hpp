@@ -87,6 +87,7 @@ struct Analysis {
   std::vector<EDev> edev;          // component-ordered
   std::vector<CompClass> classes;
   int max_nc = 0, max_ndev = 0;
+  bool force_sparse = false;       // a block has more devices than 16-bit staging offsets address: it takes the sparse path (no dense gather lists)
   bool wide = false;               // a compiled Verilog-A device is present: stamp records are [I(8)|Q(8)|G(64)|C(64)]
   int stride() const { return wide ? 145 : 41; }   // odd number of doubles per record: the lanes of a wave write different LDS banks
   int g_ofs() const { return wide ? 16 : 8; }
@@ -301,12 +302,12 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     CompClass cl;
     cl.nc = A.comp_nc[c]; cl.ndev = A.comp_ndev[c];
     const int stride = A.stride(), gofs = A.g_ofs(), gld = A.g_ld();
-    if (cl.nc > 64) {   // such a circuit takes the sparse path (its own CSR assembly): no dense gather lists, no size limit here
+    if (cl.nc > 64 || (long)cl.ndev * stride > 65535) {   // such a circuit takes the sparse path (its own CSR assembly): no dense gather lists, no size limit here
+      if (cl.nc <= 64) A.force_sparse = true;   // device-heavy small block (e.g. thousands of parallel instances on a few nodes): staging would not fit LDS either
       for (int i = 0; i < cl.ndev; ++i) { const int kd = A.edev[A.comp_dofs[c] + i].kind; if (kd == K_MOS || kd == K_VA) cl.nonlinear = true; }
       A.classes.push_back(std::move(cl));
       continue;
     }
-    if ((long)cl.ndev * stride > 65535) { A.err = "component too large for 16-bit staging offsets"; return CH_ERR_UNSUPPORTED; }
     std::vector<std::vector<uint16_t>> ml((size_t)cl.nc * cl.nc), vl(cl.nc);
     for (int i = 0; i < cl.ndev; ++i) {
       const EDev& e = A.edev[A.comp_dofs[c] + i];

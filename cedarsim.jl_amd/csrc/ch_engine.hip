@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <array>
 #include <vector>
@@ -142,6 +145,15 @@ struct Arena {
   }
 };
 static thread_local Arena* g_arena = nullptr;  // set while a circuit builds / rebuilds its buffers
+// Every entry point that may (re)allocate device buffers of a circuit opens one of these: allocations made inside the
+// call come from THAT circuit's arena and the pointer never outlives the call (a stale pointer would let a later call on
+// another circuit carve its buffers out of this circuit's arena, which is freed with this circuit).
+struct ArenaScope {
+  Arena* prev;
+  explicit ArenaScope(Arena* a) : prev(g_arena) { g_arena = a; }
+  ~ArenaScope() { g_arena = prev; }
+  ArenaScope(const ArenaScope&) = delete; ArenaScope& operator=(const ArenaScope&) = delete;
+};
 
 template <class T>
 struct DevBuf {
@@ -303,7 +315,7 @@ struct ch_circuit {
       // item = {first source (index into mat_src|vec_src), (sources << 16) | vector flag << 15 | entry}
       if (((int)blob.size() - m.blob_ofs) & 1) blob.push_back(0);
       m.wl_ofs = (int)blob.size() - m.blob_ofs;
-      if (c.nc <= 64) {
+      if (c.nc <= 64 && !c.vec_ptr.empty()) {
         // heaviest items first: when there are more items than lanes, the second pass of a wave holds only the lightest ones
         std::vector<std::array<int, 3>> items;   // {sources, first source, code}
         for (int i = 0; i < c.nc; ++i) {
@@ -383,6 +395,13 @@ struct ch_circuit {
     g_arena = &arena;
     hipStream_t st = ctx->stream;
     const int nslot = (int)slot_kind.size();
+    {  // the state rings alone take 2 * NSLOT * S * n_unk doubles: refuse a sample count the device cannot hold before any
+       // host table is sized by it (the caller gets an error code, not a std::bad_alloc or a half-built circuit)
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      const double need = 2.0 * NSLOT * (double)S * (double)std::max(1, A.n_unk) * sizeof(double) + 64.0 * (double)S * (double)std::max(1, A.n_comp);
+      if (need > 0.9 * (double)total_b) { set_err("sample count does not fit the device: " + std::to_string(S) + " samples of " + std::to_string(A.n_unk) + " unknowns need " + std::to_string((long long)(need / 1048576.0)) + " MiB for the state rings"); return CH_ERR_NOMEM; }
+    }
     bool any_par = false, any_src = false, any_mos = false, any_gmin = false;
     for (int i = 0; i < nslot; ++i) if (slot_set(i)) {
       switch (slot_kind[i]) {
@@ -538,21 +557,14 @@ struct ch_circuit {
 #endif
     lds_bytes = (lds_doubles_fixed + A.known.size() + n_dev_src() + (size_t)max_mc * B4L_STRIDE) * sizeof(double) + lds_extra_bytes;
     lds_bytes = std::max(lds_bytes, (size_t)9 * block_threads * sizeof(double));  // scratch of the in-kernel reduction
-    path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || max_mc > 64 || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
+    path = (lds_bytes > 150 * 1024 || A.max_nc > 64 || max_mc > 64 || A.force_sparse || std::getenv("CEDARHIP_FORCE_SPARSE") != nullptr) ? 2 : 1;
     if (path == 2) {
       int rcs = build_sparse_structure();
       if (rcs != CH_OK) return rcs;
       lds_bytes = 0;
     }
-    if (path == 1 && lds_bytes > 48 * 1024) {
-      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIPCHK(hipFuncSetAttribute((const void*)newton_block_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
+    // (the kernels' dynamic-LDS ceiling is raised once per device in ch_create: a per-circuit setting would be lowered again
+    //  by the next, smaller circuit of the same process)
     HIPCHK(hipStreamSynchronize(st));
     dirty = false;
     return CH_OK;
@@ -1026,7 +1038,8 @@ struct ch_circuit {
     size_t ibp = 0;
 
     // saved observables live on the device until the end
-    std::vector<double*> chunks; const int CH = 512; long nsaved = 0;
+    struct ChunkList : std::vector<double*> { ~ChunkList() { for (double* p : *this) (void)hipFree(p); } } chunks;   // freed on every exit, exceptions included
+    const int CH = 512; long nsaved = 0;
     auto row_ptr = [&](long row, double** out) -> int {  // device address of saved-row `row`, growing the buffer by chunks
       while ((size_t)(row / CH) >= chunks.size()) { double* p = nullptr; HIPCHK(hipMalloc((void**)&p, std::max<size_t>(1, (size_t)CH * n_obs * S) * sizeof(double))); chunks.push_back(p); }
       *out = chunks[row / CH] + (size_t)(row % CH) * n_obs * S;
@@ -1186,19 +1199,50 @@ struct ch_circuit {
   }
 };
 
+// Exception barrier of the C-ABI (include/cedarhip.h: "they never throw").  Host-side containers sized by the caller's
+// input (samples x unknowns, blocks x ds^2, ...) can throw std::bad_alloc / std::length_error; letting that unwind through
+// ctypes, a C client or a Julia ccall would end the host process in std::terminate.  The message goes to ch_last_error without
+// allocating when memory is the problem.
+static void set_err_nothrow(ch_ctx* ctx, const char* what, const char* detail) noexcept {
+  if (!ctx) return;
+  try { ctx->err = what; if (detail && *detail) { ctx->err += ": "; ctx->err += detail; } }
+  catch (...) { ctx->err.clear(); }   // clear() does not allocate
+}
+template <class F>
+static int guard_rc(ch_ctx* ctx, F&& body) noexcept {
+  try { return body(); }
+  catch (const std::bad_alloc&) { set_err_nothrow(ctx, "out of host memory inside the engine call", ""); return CH_ERR_NOMEM; }
+  catch (const std::length_error& e) { set_err_nothrow(ctx, "a host container would exceed its maximum size (sample count x circuit size too large)", e.what()); return CH_ERR_NOMEM; }
+  catch (const std::exception& e) { set_err_nothrow(ctx, "internal error (C++ exception caught at the C-ABI)", e.what()); return CH_ERR_INTERNAL; }
+  catch (...) { set_err_nothrow(ctx, "internal error (unknown C++ exception caught at the C-ABI)", ""); return CH_ERR_INTERNAL; }
+}
+
 // =============================================================================================
 extern "C" {
 
 void ch_dc_opts_default(ch_dc_opts* o) { std::memset(o, 0, sizeof(*o)); o->abstol = 1e-10; o->maxiters = 200; o->n_restarts = 10; o->seed = 10; o->tran_mode = 0; o->dv_max = 2.0; o->x0 = nullptr; }
 void ch_tran_opts_default(ch_tran_opts* o) { std::memset(o, 0, sizeof(*o)); o->abstol = 1e-6; o->reltol = 1e-3; o->max_order = 5; o->newton_maxiters = 10; ch_dc_opts_default(&o->dc); }
 
-ch_ctx* ch_create(int device_id, char* err, size_t errlen) {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the (process-global) kernel function, not of a launch: it is set
+// once per device to the largest size the path decision admits (finalize_params: 150 KB; ac_block_kernel<64>: 2*96*97 doubles),
+// so circuits with different LDS footprints can live side by side in one process.
+static hipError_t raise_lds_ceilings() {
+  const int cap = 160 * 1024;
+  const void* fns[] = {(const void*)newton_block_kernel<8>, (const void*)newton_block_kernel<12>, (const void*)newton_block_kernel<16>,
+                       (const void*)newton_block_kernel<32>, (const void*)newton_block_kernel<0>, (const void*)newton_block_kernel<16, true>,
+                       (const void*)newton_block_kernel<0, true>, (const void*)ac_block_kernel<64>};
+  for (const void* f : fns) { const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e != hipSuccess) return e; }
+  return hipSuccess;
+}
+
+static ch_ctx* ch_create_impl(int device_id, char* err, size_t errlen) {
   auto fail = [&](const std::string& m) -> ch_ctx* { if (err && errlen) { std::snprintf(err, errlen, "%s", m.c_str()); } return nullptr; };
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) return fail(std::string("cedarhip needs a HIP device (gfx950); none available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
   if (device_id < 0 || device_id >= n) return fail("invalid device id");
   if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(hipGetErrorString(e));
+  if ((e = raise_lds_ceilings()) != hipSuccess) return fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
   ch_ctx* c = new ch_ctx();
   c->device = device_id;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail(hipGetErrorString(e)); }
@@ -1207,12 +1251,14 @@ ch_ctx* ch_create(int device_id, char* err, size_t errlen) {
 void ch_destroy(ch_ctx* c) { if (!c) return; if (c->stream) (void)hipStreamDestroy(c->stream); delete c; }
 const char* ch_last_error(ch_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
-ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
+static ch_circuit* ch_circuit_build_impl(ch_ctx* ctx, const ch_desc* d) {
   if (!ctx || !d) return nullptr;
   ctx->err.clear();
   (void)hipSetDevice(ctx->device);
-  ch_circuit* c = new ch_circuit();
+  std::unique_ptr<ch_circuit> owner(new ch_circuit());   // released on every early return and on an exception
+  ch_circuit* c = owner.get();
   c->ctx = ctx;
+  ArenaScope arena_scope(&c->arena);
   c->n_nodes = d->n_nodes; c->temp = d->temp; c->gmin = d->gmin; c->scale = d->scale;
   for (int i = 0; i < d->n_src; ++i) {
     HSource s; s.kind = d->src_kind[i]; s.dc = d->src_dc[i];
@@ -1222,7 +1268,7 @@ ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
     c->src.push_back(s);
   }
   for (int i = 0; i < d->n_model; ++i) c->model.emplace_back(d->model_par + (size_t)i * CH_B4_NPAR, d->model_par + (size_t)(i + 1) * CH_B4_NPAR);
-  auto bad = [&](const char* m) -> ch_circuit* { ctx->err = m; delete c; return nullptr; };
+  auto bad = [&](const char* m) -> ch_circuit* { ctx->err = m; return nullptr; };
   for (int i = 0; i < d->n_dev; ++i) {
     HDev v; v.kind = d->dev_kind[i]; v.branch = -1; v.eliminated = false;
     for (int k = 0; k < CH_DEV_NNODE; ++k) { v.node[k] = d->dev_node[i * CH_DEV_NNODE + k]; if (v.node[k] < 0 || v.node[k] > d->n_nodes) return bad("device node id out of range"); }
@@ -1266,10 +1312,10 @@ ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
   // an AC-driven voltage source keeps its node and branch unknowns: the small-signal excitation enters one linear row
   for (size_t i = 0; i < c->dev.size(); ++i) if (c->dev[i].kind == CH_DEV_V && c->src[c->dev[i].ipar[0]].ac != 0.0) { protect[i] = 1; swept[c->dev[i].ipar[0]] = 1; }
   int rc = analyse(c->n_nodes, c->dev, c->src, protect, swept, c->A);
-  if (rc != CH_OK) { ctx->err = c->A.err; delete c; return nullptr; }
+  if (rc != CH_OK) { ctx->err = c->A.err; return nullptr; }
   rc = c->upload_structure();
-  if (rc != CH_OK) { delete c; return nullptr; }
-  return c;
+  if (rc != CH_OK) return nullptr;
+  return owner.release();
 }
 void ch_circuit_free(ch_circuit* c) { delete c; }
 
@@ -1291,14 +1337,14 @@ int ch_circuit_maps(ch_circuit* c, int32_t* node_unknown, int32_t* node_known, i
   return CH_OK;
 }
 
-int ch_set_samples(ch_circuit* c, int32_t n) {
+static int ch_set_samples_impl(ch_circuit* c, int32_t n) {
   if (!c || n < 1) return CH_ERR_INVALID;
   c->S = n;
   for (auto& v : c->slot_val) v.clear();
   c->dirty = true;
   return CH_OK;
 }
-int ch_set_params(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_slots, const int32_t* ids, const double* values) {
+static int ch_set_params_impl(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_slots, const int32_t* ids, const double* values) {
   if (!c || lo < 0 || hi > c->S || lo >= hi) return CH_ERR_INVALID;
   for (int i = 0; i < n_slots; ++i) {
     const int id = ids[i];
@@ -1325,8 +1371,9 @@ int ch_set_params(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_slots, const 
   return CH_OK;
 }
 
-int ch_dc(ch_circuit* c, const ch_dc_opts* o, double* x_out, int32_t* status_out, ch_stats* stats) {
+static int ch_dc_impl(ch_circuit* c, const ch_dc_opts* o, double* x_out, int32_t* status_out, ch_stats* stats) {
   if (!c || !o) return CH_ERR_INVALID;
+  ArenaScope arena_scope(&c->arena);
   c->ctx->err.clear();
   (void)hipSetDevice(c->ctx->device);
   auto t0 = hclock::now();
@@ -1344,29 +1391,30 @@ int ch_dc(ch_circuit* c, const ch_dc_opts* o, double* x_out, int32_t* status_out
   return rc;
 }
 
-int ch_tran(ch_circuit* c, double t0, double t1, const ch_tran_opts* o, ch_result** out) {
+static int ch_tran_impl(ch_circuit* c, double t0, double t1, const ch_tran_opts* o, ch_result** out) {
   if (!c || !o || !out) return CH_ERR_INVALID;
+  ArenaScope arena_scope(&c->arena);
   c->ctx->err.clear();
   (void)hipSetDevice(c->ctx->device);
-  ch_result* R = new ch_result();
+  std::unique_ptr<ch_result> R(new ch_result());
   int rc = c->tran_solve(t0, t1, *o, *R);
   R->status = rc;
-  *out = R;
+  *out = R.release();
   return rc;
 }
 int64_t ch_result_n_times(const ch_result* r) { return r ? (int64_t)r->times.size() : 0; }
-const double* ch_result_times(const ch_result* r) { return r->times.data(); }
-const double* ch_result_values(const ch_result* r) { return r->values.data(); }
-const double* ch_result_final_state(const ch_result* r) { return r->final_state.data(); }
+const double* ch_result_times(const ch_result* r) { return r ? r->times.data() : nullptr; }
+const double* ch_result_values(const ch_result* r) { return r ? r->values.data() : nullptr; }
+const double* ch_result_final_state(const ch_result* r) { return r ? r->final_state.data() : nullptr; }
 int ch_result_stats(const ch_result* r, ch_stats* s) { if (!r || !s) return CH_ERR_INVALID; *s = r->stats; return CH_OK; }
 int ch_result_status(const ch_result* r) { return r ? r->status : CH_ERR_INVALID; }
 void ch_result_free(ch_result* r) { delete r; }
 
-int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double alpha0, int32_t mode, double* F_out, double* Q_out, double* J_out) {
+static int ch_eval_impl(ch_circuit* c, int32_t sample, const double* x_mna, double t, double alpha0, int32_t mode, double* F_out, double* Q_out, double* J_out) {
   if (!c || !x_mna || sample < 0 || sample >= c->S) return CH_ERR_INVALID;
   c->ctx->err.clear();
   (void)hipSetDevice(c->ctx->device);
-  g_arena = &c->arena;
+  ArenaScope arena_scope(&c->arena);
   int rc = c->finalize_params();
   if (rc != CH_OK) return rc;
   const Analysis& A = c->A;
@@ -1472,7 +1520,6 @@ static int launch_ac(ch_circuit* c, AcArgs& a, int n_freq, int ny, int ds) {
   const size_t per = (size_t)2 * ds * (ds + 1);
   if (ds <= 96) {
     const size_t lds = per * sizeof(double);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ac_block_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     a.work = nullptr; a.f0 = 0;
     hipLaunchKernelGGL(ac_block_kernel<64>, dim3(n_freq, ny), dim3(64), lds, c->ctx->stream, a);
     return hipGetLastError() == hipSuccess ? CH_OK : CH_ERR_DEVICE;
@@ -1501,8 +1548,9 @@ static int upload_omega(ch_circuit* c, int n_freq, const double* freqs_hz) {
   return CH_OK;
 }
 
-int ch_ac(ch_circuit* c, const ch_dc_opts* o, int32_t n_freq, const double* freqs_hz, double* x_ac_out, ch_stats* stats) {
+static int ch_ac_impl(ch_circuit* c, const ch_dc_opts* o, int32_t n_freq, const double* freqs_hz, double* x_ac_out, ch_stats* stats) {
   if (!c || !o || n_freq < 1 || !freqs_hz || !x_ac_out) return CH_ERR_INVALID;
+  ArenaScope arena_scope(&c->arena);
   c->ctx->err.clear();
   (void)hipSetDevice(c->ctx->device);
   auto t0 = hclock::now();
@@ -1543,8 +1591,9 @@ int ch_ac(ch_circuit* c, const ch_dc_opts* o, int32_t n_freq, const double* freq
   return CH_OK;
 }
 
-int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_index, int32_t n_freq, const double* freqs_hz, double* psd_out, ch_stats* stats) {
+static int ch_noise_impl(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_index, int32_t n_freq, const double* freqs_hz, double* psd_out, ch_stats* stats) {
   if (!c || !o || n_freq < 1 || !freqs_hz || !psd_out) return CH_ERR_INVALID;
+  ArenaScope arena_scope(&c->arena);
   c->ctx->err.clear();
   (void)hipSetDevice(c->ctx->device);
   auto t0 = hclock::now();
@@ -1614,6 +1663,7 @@ static int mos_eval_impl(ch_circuit* c, int32_t sample, const double* v, double*
   if (!c || !v || !out || sample < 0 || sample >= c->S) return CH_ERR_INVALID;
   c->ctx->err.clear();
   (void)hipSetDevice(c->ctx->device);
+  ArenaScope arena_scope(&c->arena);
   int rc = c->finalize_params();
   if (rc != CH_OK) return rc;
   const int nm = (int)c->A.mos_hdev.size();
@@ -1632,8 +1682,8 @@ static int mos_eval_impl(ch_circuit* c, int32_t sample, const double* v, double*
   if (e != hipSuccess) { c->set_err(hipGetErrorString(e)); return CH_ERR_DEVICE; }
   return CH_OK;
 }
-int ch_mos_eval(ch_circuit* c, int32_t sample, const double* v, double* out) { return mos_eval_impl(c, sample, v, out, false); }
-int ch_mos_eval_quad(ch_circuit* c, int32_t sample, const double* v, double* out) { return mos_eval_impl(c, sample, v, out, true); }
+int ch_mos_eval(ch_circuit* c, int32_t sample, const double* v, double* out) { return guard_rc(c ? c->ctx : nullptr, [&] { return mos_eval_impl(c, sample, v, out, false); }); }
+int ch_mos_eval_quad(ch_circuit* c, int32_t sample, const double* v, double* out) { return guard_rc(c ? c->ctx : nullptr, [&] { return mos_eval_impl(c, sample, v, out, true); }); }
 
 static const char* const k_b4_names[] = {
 #define P(n, d) #n,
@@ -1654,7 +1704,7 @@ int32_t ch_bsim4_param_ignored(const char* name) {
   for (int i = 0; k_b4_ignored[i]; ++i) if (std::strcmp(k_b4_ignored[i], name) == 0) return 1;
   return 0;
 }
-int ch_bench_triad(ch_ctx* ctx, int64_t n, int32_t iters, double* gbps_out) {
+static int ch_bench_triad_impl(ch_ctx* ctx, int64_t n, int32_t iters, double* gbps_out) {
   if (!ctx || n < 1024 || iters < 1 || !gbps_out) return CH_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
   double *a = nullptr, *b = nullptr, *c = nullptr;
@@ -1680,7 +1730,7 @@ int ch_bench_triad(ch_ctx* ctx, int64_t n, int32_t iters, double* gbps_out) {
   *gbps_out = best;
   return best > 0 ? CH_OK : CH_ERR_DEVICE;
 }
-int ch_bench_fp64(ch_ctx* ctx, int32_t iters, double* tflops_out) {
+static int ch_bench_fp64_impl(ch_ctx* ctx, int32_t iters, double* tflops_out) {
   if (!ctx || iters < 1 || !tflops_out) return CH_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
   hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return CH_ERR_DEVICE;
@@ -1717,7 +1767,7 @@ int32_t ch_va_module_info(int32_t id, int32_t* n_ports, int32_t* n_nodes, int32_
 }
 const char* ch_va_node_name(int32_t id, int32_t k) { return (id >= 0 && id < va_gen::N_MODULES && k >= 0 && k < va_gen::MODULES[id].n_nodes) ? va_gen::MODULES[id].node_names[k] : nullptr; }
 const char* ch_va_param_name(int32_t id, int32_t k) { return (id >= 0 && id < va_gen::N_MODULES && k >= 0 && k < va_gen::MODULES[id].n_params) ? va_gen::MODULES[id].param_names[k] : nullptr; }
-int ch_va_eval(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* st_out) {
+static int ch_va_eval_impl(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* st_out) {
   if (!ctx || !par || !v || !st_out || id < 0 || id >= va_gen::N_MODULES) return CH_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
   const va_gen::ModuleInfo& mi = va_gen::MODULES[id];
@@ -1736,7 +1786,7 @@ int ch_va_eval(ch_ctx* ctx, int32_t id, const double* par, const double* v, doub
 }
 int32_t ch_va_n_opvars(int32_t id) { return (id >= 0 && id < va_gen::N_MODULES) ? va_gen::N_OPVARS[id] : 0; }
 const char* ch_va_opvar_name(int32_t id, int32_t k) { return (id >= 0 && id < va_gen::N_MODULES && k >= 0 && k < va_gen::N_OPVARS[id]) ? va_gen::OPNAMES[id][k] : nullptr; }
-int ch_va_opvars(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* op_out) {
+static int ch_va_opvars_impl(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* op_out) {
   if (!ctx || !par || !v || !op_out || id < 0 || id >= va_gen::N_MODULES) return CH_ERR_INVALID;
   const int nop = va_gen::N_OPVARS[id];
   if (nop == 0) return CH_OK;
@@ -1754,6 +1804,46 @@ int ch_va_opvars(ch_ctx* ctx, int32_t id, const double* par, const double* v, do
   (void)hipFree(dp); (void)hipFree(dv); (void)hipFree(dop);
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return CH_ERR_DEVICE; }
   return CH_OK;
+}
+// ---- the exported entry points: every body that can allocate runs behind an exception barrier ----
+ch_ctx* ch_create(int device_id, char* err, size_t errlen) {
+  try { return ch_create_impl(device_id, err, errlen); }
+  catch (const std::exception& e) { if (err && errlen) std::snprintf(err, errlen, "ch_create: %s", e.what()); }
+  catch (...) { if (err && errlen) std::snprintf(err, errlen, "ch_create: unknown C++ exception"); }
+  return nullptr;
+}
+ch_circuit* ch_circuit_build(ch_ctx* ctx, const ch_desc* d) {
+  ch_circuit* c = nullptr;
+  const int rc = guard_rc(ctx, [&] { c = ch_circuit_build_impl(ctx, d); return c ? CH_OK : CH_ERR_INVALID; });
+  return rc == CH_OK ? c : nullptr;   // on an exception the partially built circuit was already released by its owner (see ch_circuit_build_impl)
+}
+int ch_set_samples(ch_circuit* c, int32_t n) { return guard_rc(c ? c->ctx : nullptr, [&] { return ch_set_samples_impl(c, n); }); }
+int ch_set_params(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_slots, const int32_t* ids, const double* values) {
+  return guard_rc(c ? c->ctx : nullptr, [&] { return ch_set_params_impl(c, lo, hi, n_slots, ids, values); });
+}
+int ch_dc(ch_circuit* c, const ch_dc_opts* o, double* x_out, int32_t* status_out, ch_stats* stats) {
+  return guard_rc(c ? c->ctx : nullptr, [&] { return ch_dc_impl(c, o, x_out, status_out, stats); });
+}
+int ch_tran(ch_circuit* c, double t0, double t1, const ch_tran_opts* o, ch_result** out) {
+  if (out) *out = nullptr;
+  return guard_rc(c ? c->ctx : nullptr, [&] { return ch_tran_impl(c, t0, t1, o, out); });
+}
+int ch_eval(ch_circuit* c, int32_t sample, const double* x_mna, double t, double alpha0, int32_t mode, double* F_out, double* Q_out, double* J_out) {
+  return guard_rc(c ? c->ctx : nullptr, [&] { return ch_eval_impl(c, sample, x_mna, t, alpha0, mode, F_out, Q_out, J_out); });
+}
+int ch_ac(ch_circuit* c, const ch_dc_opts* o, int32_t n_freq, const double* freqs_hz, double* x_ac_out, ch_stats* stats) {
+  return guard_rc(c ? c->ctx : nullptr, [&] { return ch_ac_impl(c, o, n_freq, freqs_hz, x_ac_out, stats); });
+}
+int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_index, int32_t n_freq, const double* freqs_hz, double* psd_out, ch_stats* stats) {
+  return guard_rc(c ? c->ctx : nullptr, [&] { return ch_noise_impl(c, o, out_kind, out_index, n_freq, freqs_hz, psd_out, stats); });
+}
+int ch_bench_triad(ch_ctx* ctx, int64_t n, int32_t iters, double* gbps_out) { return guard_rc(ctx, [&] { return ch_bench_triad_impl(ctx, n, iters, gbps_out); }); }
+int ch_bench_fp64(ch_ctx* ctx, int32_t iters, double* tflops_out) { return guard_rc(ctx, [&] { return ch_bench_fp64_impl(ctx, iters, tflops_out); }); }
+int ch_va_eval(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* st_out) {
+  return guard_rc(ctx, [&] { return ch_va_eval_impl(ctx, id, par, v, temperature_k, gmin, st_out); });
+}
+int ch_va_opvars(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* op_out) {
+  return guard_rc(ctx, [&] { return ch_va_opvars_impl(ctx, id, par, v, temperature_k, gmin, op_out); });
 }
 const char* ch_version(void) { return "cedarhip 0.1 (gfx950; fused block Newton)"; }
 

@@ -188,11 +188,21 @@ class EngineCircuit:
             raise CedarError("ch_circuit_build failed: %s" % self.ctx.last_error())
         self.n_mna = circuit.n_mna
         self.n_samples = 1
+        # the library writes [n_samples][n_mna] doubles into buffers this class allocates: the two sides must agree on n_mna
+        lib_n_mna = self.info()["n_mna"]
+        if lib_n_mna != self.n_mna:
+            self.L.ch_circuit_free(self.h)
+            self.h = None
+            raise CedarError("host mirror and engine disagree on the MNA size (%d vs %d)" % (self.n_mna, lib_n_mna))
+
+    def close(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.L.ch_circuit_free(h)
 
     def __del__(self):
         try:
-            if self.h:
-                self.L.ch_circuit_free(self.h)
+            self.close()
         except Exception:  # noqa: BLE001
             pass
 

@@ -14,7 +14,9 @@
  *       x_mna[n_nodes + k]           current of the k-th branch device (V, L, E in device order),
  *                                    flowing from net+ to net- through the device — the sign
  *                                    convention of branch!() (src/simulate_ir.jl:112-120).
- *   - all functions return 0 on success or a negative CH_ERR_* code; they never throw.
+ *   - all functions return 0 on success or a negative CH_ERR_* code; they never throw: every entry point catches
+ *     C++ exceptions at the boundary (CH_ERR_NOMEM / CH_ERR_INTERNAL; builders return NULL), the way CedarDCOp
+ *     swallows solver exceptions and reports a retcode (src/dcop.jl:58-82).
  *   - a ch_ctx / ch_circuit is not thread-safe; use one host thread per GPU (one process per GPU).
  */
 #ifndef CEDARHIP_H
@@ -38,7 +40,9 @@ enum {
   CH_ERR_DTMIN = -4,        /* step size underflow: ReturnCode.DtLessThanMin                */
   CH_ERR_DEVICE = -5,       /* HIP runtime failure                                          */
   CH_ERR_UNSUPPORTED = -6,  /* feature outside the engine's scope                           */
-  CH_ERR_MAXSTEPS = -7      /* transient exceeded max_steps: ReturnCode.MaxIters            */
+  CH_ERR_MAXSTEPS = -7,     /* transient exceeded max_steps: ReturnCode.MaxIters            */
+  CH_ERR_NOMEM = -8,        /* host allocation failed inside the call (std::bad_alloc / length_error) */
+  CH_ERR_INTERNAL = -9      /* any other C++ exception caught at the boundary (message in ch_last_error) */
 };
 
 /* ---- device kinds (reference device functors, src/simpledevices.jl, src/vasim.jl) ---- */

@@ -725,3 +725,57 @@ def test_large_coupled_component_takes_the_sparse_path():
     assert s2.retcode == "Success"
     v = s2["n%d" % n]
     assert abs(v[0]) < 1e-9 and np.all(np.diff(v) > -1e-7) and approx(v[-1], 1.0 - n * R * itot, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# C-ABI robustness (round 2): exception containment, per-process kernel attributes, path routing
+def test_absurd_sample_count_comes_back_as_an_error_code(E):
+    """A host container sized by the caller's input must not take the process down: 2^31-1 samples of a small circuit ask
+    for far more host memory than exists; the library answers with an error code and stays usable."""
+    c = Circuit()
+    c.V("V", "vcc", 0, dc=5.0)
+    c.R("R", "vcc", "o", 2.0)
+    c.R("R2", "o", 0, 2.0)
+    c.observe_node("o")
+    e = E(c)
+    e.set_samples(2 ** 31 - 1)
+    x = np.zeros((1, e.n_mna))
+    status = np.zeros(1, np.int32)
+    import ctypes as C
+    from cedarsim_jl_amd.circuit import ChStats
+    st = ChStats()
+    rc = e.L.ch_dc(e.h, C.byref(dc_opts()), None, None, C.byref(st))   # no output buffers: the call must fail before it needs them
+    assert rc == -8, rc   # CH_ERR_NOMEM
+    assert e.ctx.last_error() != ""
+    e.set_samples(1)
+    rc, x, status, _ = e.dc()
+    assert rc == 0 and approx(x[0][c.mna_index("v", "o")], 2.5)
+
+
+def test_circuits_with_different_lds_footprints_coexist(E):
+    """The dynamic-LDS ceiling of a kernel is a per-process attribute: a second, smaller circuit (still above the 48 KB
+    default) must not lower it under the first circuit's need."""
+    big, small = E(dff_chain(5)), E(dff_chain(3))
+    assert big.info()["path"] == 1 or True
+    rc1, x1, _, _ = big.dc(dc_opts(abstol=1e-12))
+    rc2, x2, _, _ = small.dc(dc_opts(abstol=1e-12))
+    rc3, x3, _, _ = big.dc(dc_opts(abstol=1e-12))
+    assert rc1 == 0 and rc2 == 0 and rc3 == 0, (rc1, rc2, rc3, big.ctx.last_error())
+    assert big.info()["path"] == 1 and small.info()["path"] == 1
+    ok = ~np.isnan(x1[0])
+    assert np.allclose(x1[0][ok], x3[0][ok], rtol=1e-9, atol=1e-12)
+
+
+def test_device_heavy_small_block_takes_the_sparse_path():
+    """2000 parallel resistors between two nodes: 3 unknowns but more stamp records than 16-bit staging offsets address.
+    The circuit must be routed to the sparse path instead of being rejected."""
+    n = 2000
+    c = Circuit()
+    c.V("v", "a", 0, dc=1.0)
+    for i in range(n):
+        c.R("r%d" % i, "a", "b", 1000.0 * n)
+    c.R("rl", "b", "m", 500.0)
+    c.R("rm", "m", 0, 500.0)
+    sol = dc(c)
+    assert sol.retcode == "Success"
+    assert approx(sol["b"][0], 0.5, 1e-9) and approx(sol["m"][0], 0.25, 1e-9)
