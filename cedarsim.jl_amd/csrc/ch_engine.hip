@@ -1227,11 +1227,18 @@ void ch_tran_opts_default(ch_tran_opts* o) { std::memset(o, 0, sizeof(*o)); o->a
 // once per device to the largest size the path decision admits (finalize_params: 150 KB; ac_block_kernel<64>: 2*96*97 doubles),
 // so circuits with different LDS footprints can live side by side in one process.
 static hipError_t raise_lds_ceilings() {
-  const int cap = 160 * 1024;
+  const int lds_cu = 160 * 1024;   // LDS of one gfx950 CU; a kernel's static __shared__ variables come out of the same budget
   const void* fns[] = {(const void*)newton_block_kernel<8>, (const void*)newton_block_kernel<12>, (const void*)newton_block_kernel<16>,
                        (const void*)newton_block_kernel<32>, (const void*)newton_block_kernel<0>, (const void*)newton_block_kernel<16, true>,
                        (const void*)newton_block_kernel<0, true>, (const void*)ac_block_kernel<64>};
-  for (const void* f : fns) { const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap); if (e != hipSuccess) return e; }
+  for (const void* f : fns) {
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, f);
+    if (e != hipSuccess) return e;
+    const int cap = (lds_cu - (int)fa.sharedSizeBytes) & ~255;
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e != hipSuccess) return e;
+  }
   return hipSuccess;
 }
 
