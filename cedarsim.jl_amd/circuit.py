@@ -50,7 +50,8 @@ class ChStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("nf", "njacs", "nfactors", "nsolve", "nnonliniter", "nnonlinconvfail",
                                          "naccept", "nreject", "nrestarts")] + \
                [("wall_seconds", C.c_double), ("dc_seconds", C.c_double), ("device_seconds", C.c_double),
-                ("n_kernel_launches", C.c_int64), ("n_block_iters", C.c_int64)]
+                ("n_kernel_launches", C.c_int64), ("n_block_iters", C.c_int64), ("n_step_attempts", C.c_int64),
+                ("barrier_seconds", C.c_double), ("stepper", C.c_int32), ("pad_", C.c_int32)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -64,7 +65,7 @@ class ChDcOpts(C.Structure):
 class ChTranOpts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("max_order", C.c_int32), ("dtmin", C.c_double),
                 ("dtmax", C.c_double), ("dt0", C.c_double), ("max_steps", C.c_int32), ("newton_maxiters", C.c_int32),
-                ("n_saveat", C.c_int32), ("saveat", _pf64), ("dc", ChDcOpts), ("skip_dc", C.c_int32)]
+                ("n_saveat", C.c_int32), ("saveat", _pf64), ("dc", ChDcOpts), ("skip_dc", C.c_int32), ("stepper", C.c_int32)]
 
 
 class ChInfo(C.Structure):
@@ -90,8 +91,10 @@ def dc_opts(abstol=1e-10, maxiters=200, n_restarts=10, seed=10, tran_mode=False,
 
 
 def tran_opts(abstol=1e-6, reltol=1e-3, max_order=5, dtmin=0.0, dtmax=0.0, dt0=0.0, max_steps=0,
-              newton_maxiters=10, saveat=None, dc=None, skip_dc=False):
+              newton_maxiters=10, saveat=None, dc=None, skip_dc=False, stepper="auto"):
+    """stepper: "auto" | "host" | "device" — where the sequential step controller runs (include/cedarhip.h CH_STEPPER_*)."""
     o = ChTranOpts()
+    o.stepper = {"auto": 0, "host": 1, "device": 2}[stepper] if isinstance(stepper, str) else int(stepper)
     o.abstol, o.reltol, o.max_order = abstol, reltol, max_order
     o.dtmin, o.dtmax, o.dt0, o.max_steps, o.newton_maxiters = dtmin, dtmax, dt0, max_steps, newton_maxiters
     keep = None

@@ -29,6 +29,7 @@
 #include "ch_analysis.hpp"
 #include "ch_bsim4.hpp"
 #include "ch_kernels.hpp"
+#include "ch_persist.hpp"
 #include "ch_sparse.hpp"
 
 using namespace chip;
@@ -992,11 +993,143 @@ struct ch_circuit {
   }
 
   // ------------------------------------------------------------------------------------------
+  // Device-resident step controller: which circuits qualify (ch_persist.hpp header), and the launch.
+  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl;
+  int n_cu = 0;
+  bool persist_eligible(std::string& why) {
+    auto no = [&](const char* m) { why = m; return false; };
+    if (path != 1) return no("the circuit takes the sparse path");
+    if (A.n_comp < 1) return no("the circuit has no unknowns");
+    if (A.wide) return no("compiled Verilog-A devices (wide stamp records)");
+    if (!(lu_variant == 8 || lu_variant == 12 || lu_variant == 16)) return no("a Jacobian block has more than 16 unknowns");
+    if (block_threads != 64 || max_mc > 8) return no("a block needs more than one wavefront of device slots or more than 8 MOSFET classes");
+    if (Ssrc != 1) return no("per-sample source parameters");
+    if (needed_src.size() > (size_t)P_MAXSRC || A.known.size() > 64 || n_dev_src() > 64) return no("more than 64 sources / known nodes");
+    if (!(S == 1 || A.n_comp == 1)) return no("several blocks per sample in a multi-sample batch");
+    for (const ClassMeta& m : h_cms) if (m.nslots > 64 || m.nc > lu_variant || m.n_work <= 0) return no("a block class does not fit the one-wave register path");
+    if (n_cu == 0) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return no("hipGetDeviceProperties failed"); n_cu = prop.multiProcessorCount; }
+    const long nblk = (long)A.n_comp * S;
+    if (nblk > (long)PW * n_cu) return no("more blocks than resident wavefronts (4 per CU)");
+    size_t npwl = 0; for (int i : needed_src) npwl += src[i].ts.size();
+    if (npwl > 2048) return no("piecewise-linear tables above 2048 points");
+    return true;
+  }
+  size_t persist_wave_doubles() const {
+    return lds_doubles_fixed + 16 * (size_t)A.max_nc + 10 + 48 + P_MAXSRC + A.known.size() + n_dev_src() + (size_t)max_mc * B4L_STRIDE + (lds_extra_bytes + 7) / 8 + 2;
+  }
+  int tran_persistent(double t0, double t1, const ch_tran_opts& o, ch_result& R, const std::vector<double>& bps, int kmax, double dtmin, double dtmax,
+                      int max_steps, int nmaxit, hclock::time_point tstart, bool& used) {
+    used = false;
+    hipStream_t st = ctx->stream;
+    g_arena = &arena;
+    const int n_obs = R.n_obs;
+    const int nblk = A.n_comp * S, n_wg = (nblk + PW - 1) / PW;
+    // ---- constants blob: needed sources, known-node definitions, device-source map, PWL tables ----
+    std::vector<int> ci; std::vector<double> cd;
+    {
+      const int nsrc = (int)src.size(), nk = (int)A.known.size(), nds = n_dev_src();
+      std::vector<int> pos(std::max(1, nsrc), -1);
+      for (size_t i = 0; i < needed_src.size(); ++i) pos[needed_src[i]] = (int)i;
+      std::vector<double> pt, py;
+      ci = {(int)needed_src.size(), nk, nds, 0};
+      for (int i : needed_src) { ci.push_back(src[i].kind); ci.push_back((int)pt.size()); ci.push_back((int)src[i].ts.size()); pt.insert(pt.end(), src[i].ts.begin(), src[i].ts.end()); py.insert(py.end(), src[i].ys.begin(), src[i].ys.end()); }
+      ci[3] = (int)pt.size();
+      std::vector<int> kptr(1, 0), kidx; std::vector<double> kcoef;
+      for (int k = 0; k < nk; ++k) { for (auto& tm : A.known[k].terms) { kidx.push_back(pos[tm.first]); kcoef.push_back(tm.second); } kptr.push_back((int)kidx.size()); }
+      ci.insert(ci.end(), kptr.begin(), kptr.end()); ci.insert(ci.end(), kidx.begin(), kidx.end());
+      for (int j = 0; j < nds; ++j) ci.push_back(j < (int)dev_src.size() ? pos[dev_src[j]] : 0);
+      for (int i : needed_src) for (int k = 0; k < CH_SRC_NPAR; ++k) cd.push_back(h_src_par[(size_t)i * CH_SRC_NPAR + k]);
+      cd.insert(cd.end(), kcoef.begin(), kcoef.end()); cd.insert(cd.end(), pt.begin(), pt.end()); cd.insert(cd.end(), py.begin(), py.end());
+      for (int v : ci) if (v < 0) { set_err("internal: a needed source is missing from the evaluation list"); return CH_ERR_INTERNAL; }
+    }
+    const size_t wave_d = persist_wave_doubles();
+    const size_t lds = (cd.size() + (ci.size() + 1) / 2 + PW * P_NREC + P_NREC + PW * wave_d) * sizeof(double);
+    if (lds > 150 * 1024) { set_err("device-resident stepper: the workgroup's LDS footprint exceeds 150 KB"); return CH_OK; }
+    // ---- output rows ----
+    const size_t row_d = std::max<size_t>(1, (size_t)n_obs * S);
+    long long max_rows;
+    if (o.n_saveat > 0) max_rows = (long long)o.n_saveat + 1;
+    else max_rows = std::min<long long>((long long)max_steps + 2, std::max<long long>(1024, std::min<long long>(1 << 20, (long long)((256u << 20) / (row_d * sizeof(double))))));
+    if (o.n_saveat == 0 && std::getenv("CEDARHIP_PERSIST_MAXROWS")) max_rows = std::max(2L, std::atol(std::getenv("CEDARHIP_PERSIST_MAXROWS")));   // test hook: forces the drain-and-resume path
+    HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(bps, st));
+    { std::vector<double> sv(o.saveat, o.saveat + std::max(0, o.n_saveat)); if (sv.empty()) sv.push_back(0.0); HIPCHK(d_psave.upload(sv, st)); }
+    HIPCHK(d_ptimes.alloc((size_t)max_rows)); HIPCHK(d_prows.alloc((size_t)max_rows * row_d));
+    HIPCHK(d_wgrec.alloc((size_t)n_wg * P_NREC)); HIPCHK(d_grprec.alloc(8 * P_NREC)); HIPCHK(d_pcnt.alloc(10 * 32)); HIPCHK(d_pctl.alloc(1));
+    PersistArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.a = base;
+    pa.a.mode = MODE_TRAN; pa.a.maxit = nmaxit; pa.a.abstol = o.abstol; pa.a.reltol = o.reltol; pa.a.newton_tol = 0.1; pa.a.active = nullptr; pa.a.gshunt = 0.0;
+    pa.nblk = nblk; pa.n_wg = n_wg; pa.red_max = (S > 1) ? 1 : 0; pa.wave_doubles = (int)wave_d;
+    pa.t1 = t1; pa.dtmin = dtmin; pa.dtmax = dtmax; pa.first_frac = 1e-3; pa.kmax = kmax; pa.max_steps = max_steps;
+    pa.bps = d_pbps.p; pa.nbp = (int)bps.size(); pa.saveat = d_psave.p; pa.n_saveat = o.n_saveat;
+    pa.ci = d_pci.p; pa.cd = d_pcd.p; pa.n_ci = (int)ci.size(); pa.n_cd = (int)cd.size();
+    pa.out_times = d_ptimes.p; pa.out_rows = d_prows.p; pa.max_rows = max_rows; pa.n_obs = n_obs;
+    pa.ctl = d_pctl.p; pa.wg_rec = d_wgrec.p; pa.grp_rec = d_grprec.p; pa.counters = d_pcnt.p;
+    pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz
+    // initial controller state (same first step as the host stepper)
+    TranCtl cs; std::memset(&cs, 0, sizeof(cs));
+    const double span = t1 - t0;
+    double h = o.dt0 > 0 ? o.dt0 : std::min(dtmax, 1e-3 * span);
+    h = std::max(10 * dtmin, std::min(h, (bps[0] - t0) / 50.0) * 1e-3);
+    cs.t = t0; cs.h = h; cs.k = 1; cs.nhist = 1; cs.reset_rate = 1; cs.tslot[0] = t0;
+    const void* fn = lu_variant == 8 ? (const void*)tran_persistent_kernel<8> : lu_variant == 12 ? (const void*)tran_persistent_kernel<12> : (const void*)tran_persistent_kernel<16>;
+    {
+      hipFuncAttributes fa;
+      HIPCHK(hipFuncGetAttributes(&fa, fn));
+      if (lds + fa.sharedSizeBytes > 160 * 1024) { set_err("device-resident stepper: LDS footprint"); return CH_OK; }
+      HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((160 * 1024 - (int)fa.sharedSizeBytes) & ~255)));
+    }
+    std::vector<double> hrows, htimes;
+    std::vector<std::vector<double>> row_store;   // drained batches when the row buffer fills (no saveat)
+    int resume = 0, status = CH_OK;
+    for (;;) {
+      HIPCHK(hipMemcpyAsync(d_pctl.p, &cs, sizeof(cs), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemsetAsync(d_pcnt.p, 0, 10 * 32 * sizeof(unsigned), st));
+      pa.resume = resume;
+      void* kargs[] = {(void*)&pa};
+      HIPCHK(hipEventRecord(ev0, st));
+      const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(n_wg), dim3(PW * 64), kargs, (unsigned)lds, st);
+      if (le != hipSuccess) {
+        (void)hipGetLastError();
+        if (resume == 0) { set_err(std::string("cooperative launch refused: ") + hipGetErrorString(le)); return CH_OK; }   // fall back to the host stepper
+        set_err(std::string("device-resident stepper: relaunch failed: ") + hipGetErrorString(le)); used = true; return CH_ERR_DEVICE;
+      }
+      HIPCHK(hipEventRecord(ev1, st));
+      used = true;
+      { const hipError_t se = hipStreamSynchronize(st); if (se != hipSuccess) { set_err(std::string("device-resident stepper: ") + hipGetErrorString(se)); return CH_ERR_DEVICE; } }
+      { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); persist_ms += ms; persist_launches += 1; }
+      HIPCHK(hipMemcpy(&cs, d_pctl.p, sizeof(cs), hipMemcpyDeviceToHost));
+      // rows of this launch
+      const size_t nr = (size_t)cs.nsaved;
+      const size_t base_t = htimes.size();
+      htimes.resize(base_t + nr); hrows.resize((base_t + nr) * row_d);
+      if (nr > 0) {
+        HIPCHK(hipMemcpy(htimes.data() + base_t, d_ptimes.p, nr * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hrows.data() + base_t * row_d, d_prows.p, nr * row_d * sizeof(double), hipMemcpyDeviceToHost));
+      }
+      if (cs.exit_reason == PX_ROWS_FULL) { cs.nsaved = 0; resume = 1; continue; }
+      if (cs.exit_reason == PX_ABORT) { set_err("device-resident stepper: a grid-wide wait exceeded its bound (workgroups not co-resident?)"); status = CH_ERR_DEVICE; }
+      else status = cs.status;
+      break;
+    }
+    persist_attempts = cs.n_attempts;
+    persist_barrier_s = (double)cs.t_cycles_barrier * 1e-8;
+    R.stats.naccept += cs.naccept; R.stats.nreject += cs.nreject; R.stats.nnonlinconvfail += cs.nconvfail;
+    R.stats.n_block_iters += cs.sum_block_iters; R.stats.nnonliniter += cs.sum_iters; R.stats.nf += cs.sum_iters; R.stats.njacs += cs.sum_iters;
+    R.stats.nfactors += cs.sum_iters; R.stats.nsolve += cs.sum_iters;
+    const size_t nt = htimes.size();
+    R.times = htimes;
+    R.values.assign((size_t)n_obs * nt * S, 0.0);
+    for (size_t r = 0; r < nt; ++r) for (int ob = 0; ob < n_obs; ++ob) std::memcpy(&R.values[((size_t)ob * nt + r) * S], &hrows[(r * n_obs + ob) * S], S * sizeof(double));
+    return finish_tran(R, 0, cs.t, status, tstart);
+  }
+
+  // ------------------------------------------------------------------------------------------
   int tran_solve(double t0, double t1, const ch_tran_opts& o, ch_result& R) {
     auto tstart = hclock::now();
     std::memset(&R.stats, 0, sizeof(R.stats));
     R.S = S; R.n_obs = (int)obs_kind.size();
     device_ms = 0; n_launch = 0; n_timed = 0;
+    persist_ms = 0; persist_launches = 0; persist_attempts = 0; persist_barrier_s = 0;
     int rc = finalize_params();
     if (rc != CH_OK) return rc;
     hipStream_t st = ctx->stream;
@@ -1036,6 +1169,23 @@ struct ch_circuit {
     std::sort(bps.begin(), bps.end());
     bps.erase(std::unique(bps.begin(), bps.end()), bps.end());
     size_t ibp = 0;
+
+    // ---- device-resident step controller (ch_persist.hpp) where the circuit qualifies ----
+    {
+      const char* ev = std::getenv("CEDARHIP_STEPPER");
+      int want = o.stepper;
+      if (want == CH_STEPPER_AUTO && ev) want = std::strcmp(ev, "host") == 0 ? CH_STEPPER_HOST : (std::strcmp(ev, "device") == 0 ? CH_STEPPER_DEVICE : CH_STEPPER_AUTO);
+      if (want != CH_STEPPER_HOST) {
+        std::string why;
+        if (persist_eligible(why)) {
+          bool used = false;
+          rc = tran_persistent(t0, t1, o, R, bps, kmax, dtmin, dtmax, max_steps, nmaxit, tstart, used);
+          if (used) return rc;
+          why = err();
+        }
+        if (want == CH_STEPPER_DEVICE) { set_err("device-resident stepper not available for this circuit: " + why); return CH_ERR_UNSUPPORTED; }
+      }
+    }
 
     // saved observables live on the device until the end
     struct ChunkList : std::vector<double*> { ~ChunkList() { for (double* p : *this) (void)hipFree(p); } } chunks;   // freed on every exit, exceptions included
@@ -1101,6 +1251,7 @@ struct ch_circuit {
       if (o.n_saveat == 0 && n_obs > 0) { rc = row_ptr(nsaved, &a.obs_row); if (rc != CH_OK) { status = rc; break; } }  // candidate row, kept on accept
       Summary sm;
       rc = run_newton(a, nullptr, sm); if (rc != CH_OK) { status = rc; break; }
+      R.stats.n_step_attempts++;
       R.stats.n_block_iters += sm.sum_block_iters; R.stats.nnonliniter += sm.sum_iters; R.stats.nf += sm.sum_iters; R.stats.njacs += sm.sum_iters; R.stats.nfactors += sm.sum_iters; R.stats.nsolve += sm.sum_iters;
       if (sm.n_fail > 0) {
         R.stats.nnonlinconvfail++; reset_rate = true;
@@ -1167,6 +1318,16 @@ struct ch_circuit {
           std::memcpy(&R.values[((size_t)ob * nt + cidx * CH + r) * S], &buf[(r * n_obs + ob) * S], S * sizeof(double));
       }
       free_chunks();
+    }
+    return finish_tran(R, order[0], t, status, tstart);
+  }
+
+  // shared end of both step controllers: derived observables, final state, statistics
+  double persist_ms = 0; long persist_launches = 0; long long persist_attempts = 0; double persist_barrier_s = 0;
+  int finish_tran(ch_result& R, int newest_slot, double t, int status, hclock::time_point tstart) {
+    const int n_obs = R.n_obs;
+    const size_t nt = R.times.size();
+    {
       // several observables fed by one unknown (merged nodes): the kernel writes the primary one only
       for (int ob = 0; ob < n_obs; ++ob) if (obs_primary[ob] != ob)
         std::memcpy(&R.values[(size_t)ob * nt * S], &R.values[(size_t)obs_primary[ob] * nt * S], nt * S * sizeof(double));
@@ -1184,7 +1345,7 @@ struct ch_circuit {
       }
     }
     R.final_state.assign((size_t)S * A.n_mna, 0.0);
-    download_mna(order[0], t, 1, R.final_state.data());
+    download_mna(newest_slot, t, 1, R.final_state.data());
 #ifdef CH_STAMPS
     { unsigned long long hs[8]; (void)hipMemcpy(hs, d_stamps.p, sizeof(hs), hipMemcpyDeviceToHost);
       std::fprintf(stderr, "[stamps] cycles summed over blocks: prologue %llu eval %llu gather %llu solve %llu epilogue %llu arrival %llu pre-LU %llu LU %llu ; launches %ld blocks %d\n", hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7], n_launch, A.n_comp * S); }
@@ -1192,8 +1353,10 @@ struct ch_circuit {
     R.status = status;
     R.stats.wall_seconds = std::chrono::duration<double>(hclock::now() - tstart).count();
     if (host_profile) { std::fprintf(stderr, "[host profile] wall %.3f ms; in run_newton: launch %.3f ms, wait %.3f ms, events+reduce %.3f ms; launches %ld\n", 1e3 * R.stats.wall_seconds, 1e3 * prof_launch, 1e3 * prof_wait, 1e3 * prof_reduce, n_launch); prof_launch = prof_wait = prof_reduce = 0; }
-    R.stats.device_seconds = n_timed > 0 ? device_ms * 1e-3 * (double)n_launch / (double)n_timed : 0.0;  // scaled from the sampled launches
-    R.stats.n_kernel_launches = n_launch;
+    R.stats.device_seconds = (n_timed > 0 ? device_ms * 1e-3 * (double)n_launch / (double)n_timed : 0.0) + persist_ms * 1e-3;  // sampled launches scaled + the persistent launches (exact)
+    R.stats.n_kernel_launches = n_launch + persist_launches;
+    R.stats.n_step_attempts += persist_attempts; R.stats.barrier_seconds = persist_barrier_s;
+    R.stats.stepper = persist_launches > 0 ? CH_STEPPER_DEVICE : CH_STEPPER_HOST;
     if (status != CH_OK && err().empty()) set_err(status == CH_ERR_DTMIN ? "step size underflow (DtLessThanMin)" : "transient did not reach t1");
     return status;
   }

@@ -314,11 +314,11 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     if (mine) {
       dml[lane] = a.dmask[uofs + lane] | ((a.unk_obs[uofs + lane] + 1) << 8);
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {   // global slot j holds the j-th newest point (canonical order)
-        Xh[j * nc + lane] = a.X[(long)j * a.slot_stride + sofs + lane];
-        Qh[j * nc + lane] = a.Qh[(long)j * a.slot_stride + sofs + lane];
+      for (int j = 0; j < 7; ++j) {   // global slot j holds the j-th newest point (canonical order); with head = 0 that is ring slot (-j) & 7
+        Xh[((8 - j) & 7) * nc + lane] = a.X[(long)j * a.slot_stride + sofs + lane];
+        Qh[((8 - j) & 7) * nc + lane] = a.Qh[(long)j * a.slot_stride + sofs + lane];
       }
-      Xh[7 * nc + lane] = 0.0; Qh[7 * nc + lane] = 0.0;
+      Xh[1 * nc + lane] = 0.0; Qh[1 * nc + lane] = 0.0;   // ring slot 1 = first candidate
     }
   }
   // ---- controller state (identical in every wave) ----
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   }
   double tsl[8];   // times by ring slot
 #pragma unroll
-  for (int j = 0; j < 8; ++j) tsl[j] = p.ctl->tslot[j];
+  for (int j = 0; j < 8; ++j) tsl[(8 - j) & 7] = p.ctl->tslot[j];   // canonical (newest first) -> ring slots, head = 0
   double rate_prev = 1.0;
   wave_fence();
   __syncthreads();

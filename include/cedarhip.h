@@ -159,6 +159,10 @@ typedef struct ch_stats {
   double device_seconds;   /* sum of dominant-kernel durations measured with HIP events (0 for oracle) */
   int64_t n_kernel_launches;
   int64_t n_block_iters;   /* Newton iterations summed over every Jacobian block (exact work count) */
+  int64_t n_step_attempts; /* time-step attempts (accepted + rejected + Newton failures)                */
+  double barrier_seconds;  /* device-resident stepper: time one wave spent inside the grid-wide reductions (0 otherwise) */
+  int32_t stepper;         /* which step controller ran: CH_STEPPER_HOST or CH_STEPPER_DEVICE (0 for DC-only calls) */
+  int32_t pad_;
 } ch_stats;
 
 /* CedarDCOp options (src/dcop.jl:24-28, 53-94) */
@@ -186,7 +190,14 @@ typedef struct ch_tran_opts {
   const double* saveat;    /* [n_saveat] increasing times to save (dense output by interpolation) */
   ch_dc_opts dc;           /* initialisation (CedarDCOp) */
   int32_t skip_dc;         /* 1: start from dc.x0 as given (u0 passed by the caller, test/common.jl:36-43) */
+  int32_t stepper;         /* CH_STEPPER_AUTO (default): device-resident controller where the circuit qualifies, host otherwise;
+                              CH_STEPPER_HOST / CH_STEPPER_DEVICE force one (DEVICE fails with CH_ERR_UNSUPPORTED when it cannot run) */
 } ch_tran_opts;
+
+/* Where the sequential step controller of ch_tran runs (the policy is the same): on the host with one kernel
+ * launch per step attempt, or inside ONE persistent cooperative launch per transient (blocks stay resident, the
+ * accept/reject/order/step decision is taken from a grid-wide reduction by every wavefront identically). */
+enum { CH_STEPPER_AUTO = 0, CH_STEPPER_HOST = 1, CH_STEPPER_DEVICE = 2 };
 
 typedef struct ch_ctx ch_ctx;
 typedef struct ch_circuit ch_circuit;

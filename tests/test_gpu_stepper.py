@@ -1,0 +1,130 @@
+"""Device-resident step controller (cedarsim.jl_amd/csrc/ch_persist.hpp) against the host stepper of the same engine
+(same policy, two implementations: one launch per attempt vs one persistent cooperative launch per transient) and against the
+closed forms / the oracle.  Tolerances as everywhere: 1e-4 of the swing on transient waveforms."""
+import os
+
+import numpy as np
+import pytest
+
+from cedarsim_jl_amd import PULSE, PWL, SIN, Circuit, dc_opts, tran_opts
+from cedarsim_jl_amd.workloads import DFF_CHECK_Q, DFF_CHECK_TIMES, DFF_TSPAN, dff_array
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from cedarsim_jl_amd.engine import EngineCircuit, load_library
+    load_library()
+    return EngineCircuit
+
+
+def run(e, tspan, stepper, **kw):
+    rc, t, v, xf, st = e.tran(tspan[0], tspan[1], tran_opts(stepper=stepper, **kw))
+    assert rc == 0, (rc, e.ctx.last_error())
+    return t, v, xf, st
+
+
+def test_single_dff_device_stepper_matches_host_stepper(E):
+    e = E(dff_array(1, observe="q0"))
+    sv = np.linspace(0.0, 7e-7, 701)
+    kw = dict(abstol=1e-7, reltol=1e-7, saveat=sv, dc=dc_opts(abstol=1e-14))
+    th, vh, xh, sth = run(e, DFF_TSPAN, "host", **kw)
+    td, vd, xd, std = run(e, DFF_TSPAN, "device", **kw)
+    assert sth["stepper"] == 1 and std["stepper"] == 2
+    assert np.array_equal(th, td) and np.array_equal(td, sv)
+    assert np.max(np.abs(vh - vd)) < 1e-4 * 5.0, np.max(np.abs(vh - vd))
+    ok = ~np.isnan(xh[0])
+    assert np.allclose(xh[0][ok], xd[0][ok], rtol=1e-4, atol=5e-4)
+    # same policy: the two controllers take (nearly) the same number of steps
+    assert abs(std["naccept"] - sth["naccept"]) <= 0.02 * sth["naccept"] + 3, (std["naccept"], sth["naccept"])
+    assert std["n_kernel_launches"] < 20 and sth["n_kernel_launches"] > 500
+    assert std["n_step_attempts"] == std["naccept"] + std["nreject"] + std["nnonlinconvfail"]
+
+
+def test_array_on_the_device_stepper_gate_and_identical_tiles(E):
+    e = E(dff_array(64, observe="q"))
+    t, v, xf, st = run(e, DFF_TSPAN, "device", abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14))
+    assert st["stepper"] == 2 and v.shape[0] == 64
+    assert np.max(np.abs(v - v[0:1])) < 1e-9   # tile equivalence (the DC restarts start every block from its own 1e-7*randn)
+    q = [float(np.interp(tt, t, v[0, :, 0])) for tt in DFF_CHECK_TIMES]
+    assert all(abs(a - b) <= 10 * 1e-4 for a, b in zip(q, DFF_CHECK_Q)), q
+    # every accepted step saved: times strictly increasing, ending at t1
+    assert np.all(np.diff(t) > 0) and t[0] == 0.0 and t[-1] == DFF_TSPAN[1] and len(t) == st["naccept"] + 1
+
+
+def test_linear_circuits_with_every_waveform_kind_on_the_device_stepper(E):
+    """RC low-pass driven by PWL, PULSE and SIN sources: device-resident vs host stepper on a saveat grid, and the PWL case
+    against its closed form (test/transients.jl:17-62)."""
+    def rc(wave):
+        c = Circuit()
+        c.V("v", "in", 0, dc=0.0, tran=wave)
+        c.R("r", "in", "o", 1e3)
+        c.C("c", "o", 0, 1e-9)
+        c.observe_node("o")
+        return c
+    sv = np.linspace(0.0, 2e-5, 401)
+    waves = [PWL([0.0, 0.0, 1e-6, 1.0, 1.2e-5, 1.0, 1.3e-5, 0.0]), PULSE(0.0, 1.0, 1e-6, 1e-7, 2e-7, 3e-6, 8e-6), SIN(0.2, 1.0, 2e5, 1e-6, 1e5, 30.0, 3.0)]
+    for w in waves:
+        e = E(rc(w))
+        kw = dict(abstol=1e-9, reltol=1e-7, saveat=sv)
+        th, vh, _, sth = run(e, (0.0, 2e-5), "host", **kw)
+        td, vd, _, std = run(e, (0.0, 2e-5), "device", **kw)
+        assert std["stepper"] == 2
+        assert np.max(np.abs(vh - vd)) < 1e-5, (type(w).__name__, np.max(np.abs(vh - vd)))
+    # closed form of the first ramp: v(t) = (t - t0) - tau (1 - exp(-(t - t0)/tau)) per volt/second of slope, tau = 1 us
+    e = E(rc(waves[0]))
+    td, vd, _, _ = run(e, (0.0, 2e-5), "device", abstol=1e-10, reltol=1e-8, saveat=sv)
+    tau, slope = 1e-6, 1e6
+    m = (sv >= 0.0) & (sv <= 1e-6)
+    ref = slope * (sv[m] - tau * (1.0 - np.exp(-sv[m] / tau)))
+    assert np.max(np.abs(vd[0, m, 0] - ref)) < 1e-6
+
+
+def test_monte_carlo_batch_on_the_device_stepper(E):
+    """n_comp == 1, many samples: per-sample error norms, maximum over samples (lock-step batch) — device vs host stepper."""
+    from cedarsim_jl_amd import bsim4_params as B4
+    ckt = dff_array(1, observe="q0")
+    rng = np.random.default_rng(7)
+    S = 96
+    slots, vals = [], []
+    for mname in ("nfet_06v0", "pfet_06v0"):
+        bv = ckt.models[ckt.model_names.index(mname)][B4.PARAM_INDEX["vth0"]]
+        slots.append(ckt.slot(mname, "vth0"))
+        vals.append(bv * (1.0 + 0.02 * rng.standard_normal(S)))
+    e = E(ckt)
+    e.set_samples(S)
+    e.set_params(slots, vals)
+    sv = np.linspace(0.0, 7e-7, 141)
+    kw = dict(abstol=1e-6, reltol=1e-6, saveat=sv, dc=dc_opts(abstol=1e-14))
+    th, vh, _, sth = run(e, DFF_TSPAN, "host", **kw)
+    td, vd, _, std = run(e, DFF_TSPAN, "device", **kw)
+    assert std["stepper"] == 2 and vd.shape == (1, 141, S)
+    assert np.max(np.abs(vh - vd)) < 1e-4 * 5.0, np.max(np.abs(vh - vd))
+    assert len({tuple(np.round(vd[0, :, s], 9)) for s in range(S)}) > S // 2   # the samples really differ
+
+
+def test_row_buffer_drain_and_resume(E):
+    """Without saveat every accepted step is a row; when the device row buffer fills, the kernel stops with its controller state
+    and history written back and the host relaunches it (resume): the result must not depend on where the cuts fall."""
+    e = E(dff_array(2, observe="q"))
+    kw = dict(abstol=1e-5, reltol=1e-5, dc=dc_opts(abstol=1e-14))
+    t1, v1, x1, st1 = run(e, DFF_TSPAN, "device", **kw)
+    os.environ["CEDARHIP_PERSIST_MAXROWS"] = "100"
+    try:
+        t2, v2, x2, st2 = run(e, DFF_TSPAN, "device", **kw)
+    finally:
+        del os.environ["CEDARHIP_PERSIST_MAXROWS"]
+    assert st2["n_kernel_launches"] > st1["n_kernel_launches"] + 5
+    assert len(t1) > 300 and abs(len(t1) - len(t2)) <= 0.03 * len(t1) + 3
+    g = np.linspace(0.0, 7e-7, 1401)
+    assert np.max(np.abs(np.interp(g, t1, v1[0, :, 0]) - np.interp(g, t2, v2[0, :, 0]))) < 1e-3 * 5.0
+
+
+def test_device_stepper_is_refused_where_it_cannot_run(E):
+    from cedarsim_jl_amd.workloads import dff_chain
+    e = E(dff_chain(2))   # one coupled 22-unknown block: LDS LU, not the register path
+    rc, t, v, xf, st = e.tran(0.0, 1e-8, tran_opts(stepper="device"))
+    assert rc == -6 and "device-resident stepper" in e.ctx.last_error()
+    rc, t, v, xf, st = e.tran(0.0, 1e-8, tran_opts())   # auto: falls back to the host stepper
+    assert rc == 0 and st["stepper"] == 1
