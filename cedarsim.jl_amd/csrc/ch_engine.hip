@@ -1004,7 +1004,7 @@ struct ch_circuit {
     if (!(lu_variant == 8 || lu_variant == 12 || lu_variant == 16)) return no("a Jacobian block has more than 16 unknowns");
     if (block_threads != 64 || max_mc > 8) return no("a block needs more than one wavefront of device slots or more than 8 MOSFET classes");
     if (Ssrc != 1) return no("per-sample source parameters");
-    if (needed_src.size() > (size_t)P_MAXSRC || A.known.size() > 64 || n_dev_src() > 64) return no("more than 64 sources / known nodes");
+    if (needed_src.size() > (size_t)P_MAXSRC || A.known.size() + (size_t)n_dev_src() > 64) return no("more than 64 sources / known-node and source values per attempt");
     if (!(S == 1 || A.n_comp == 1)) return no("several blocks per sample in a multi-sample batch");
     for (const ClassMeta& m : h_cms) if (m.nslots > 64 || m.nc > lu_variant || m.n_work <= 0) return no("a block class does not fit the one-wave register path");
     if (n_cu == 0) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return no("hipGetDeviceProperties failed"); n_cu = prop.multiProcessorCount; }
@@ -1031,15 +1031,16 @@ struct ch_circuit {
       std::vector<int> pos(std::max(1, nsrc), -1);
       for (size_t i = 0; i < needed_src.size(); ++i) pos[needed_src[i]] = (int)i;
       std::vector<double> pt, py;
-      ci = {(int)needed_src.size(), nk, nds, 0};
+      ci = {(int)needed_src.size(), nk + nds, 0, 0};
       for (int i : needed_src) { ci.push_back(src[i].kind); ci.push_back((int)pt.size()); ci.push_back((int)src[i].ts.size()); pt.insert(pt.end(), src[i].ts.begin(), src[i].ts.end()); py.insert(py.end(), src[i].ys.begin(), src[i].ys.end()); }
-      ci[3] = (int)pt.size();
-      std::vector<int> kptr(1, 0), kidx; std::vector<double> kcoef;
-      for (int k = 0; k < nk; ++k) { for (auto& tm : A.known[k].terms) { kidx.push_back(pos[tm.first]); kcoef.push_back(tm.second); } kptr.push_back((int)kidx.size()); }
-      ci.insert(ci.end(), kptr.begin(), kptr.end()); ci.insert(ci.end(), kidx.begin(), kidx.end());
-      for (int j = 0; j < nds; ++j) ci.push_back(j < (int)dev_src.size() ? pos[dev_src[j]] : 0);
+      ci[2] = (int)pt.size();
+      // entries: the nk known-node values, then the nds device source values (kvl and svl are contiguous in LDS)
+      std::vector<int> eptr(1, 0), eidx; std::vector<double> ecoef;
+      for (int k = 0; k < nk; ++k) { for (auto& tm : A.known[k].terms) { eidx.push_back(pos[tm.first]); ecoef.push_back(tm.second); } eptr.push_back((int)eidx.size()); }
+      for (int j = 0; j < nds; ++j) { if (j < (int)dev_src.size()) { eidx.push_back(pos[dev_src[j]]); ecoef.push_back(1.0); } eptr.push_back((int)eidx.size()); }
+      ci.insert(ci.end(), eptr.begin(), eptr.end()); ci.insert(ci.end(), eidx.begin(), eidx.end());
       for (int i : needed_src) for (int k = 0; k < CH_SRC_NPAR; ++k) cd.push_back(h_src_par[(size_t)i * CH_SRC_NPAR + k]);
-      cd.insert(cd.end(), kcoef.begin(), kcoef.end()); cd.insert(cd.end(), pt.begin(), pt.end()); cd.insert(cd.end(), py.begin(), py.end());
+      cd.insert(cd.end(), ecoef.begin(), ecoef.end()); cd.insert(cd.end(), pt.begin(), pt.end()); cd.insert(cd.end(), py.begin(), py.end());
       for (int v : ci) if (v < 0) { set_err("internal: a needed source is missing from the evaluation list"); return CH_ERR_INTERNAL; }
     }
     const size_t wave_d = persist_wave_doubles();
@@ -1113,6 +1114,12 @@ struct ch_circuit {
     }
     persist_attempts = cs.n_attempts;
     persist_barrier_s = (double)cs.t_cycles_barrier * 1e-8;
+#ifdef CH_STAMPS
+    { static const char* nm[12] = {"set-up", "coefficients", "sources", "predictor", "eval", "gather", "rows+norm", "LU+solves", "update", "candidate", "grid-reduce", "controller"};
+      std::fprintf(stderr, "[pstamps] attempts %lld; cycles per attempt (wave 0 of workgroup 0):", cs.n_attempts);
+      for (int q = 0; q < 12; ++q) std::fprintf(stderr, " %s %.0f", nm[q], (double)cs.stamps[q] / (double)std::max<long long>(1, cs.n_attempts));
+      std::fprintf(stderr, "\n"); }
+#endif
     R.stats.naccept += cs.naccept; R.stats.nreject += cs.nreject; R.stats.nnonlinconvfail += cs.nconvfail;
     R.stats.n_block_iters += cs.sum_block_iters; R.stats.nnonliniter += cs.sum_iters; R.stats.nf += cs.sum_iters; R.stats.njacs += cs.sum_iters;
     R.stats.nfactors += cs.sum_iters; R.stats.nsolve += cs.sum_iters;

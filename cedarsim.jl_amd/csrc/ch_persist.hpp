@@ -19,6 +19,12 @@
 
 #include "ch_kernels.hpp"
 
+#ifdef CH_STAMPS
+#define P_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); pacc_[slot] += now_ - plast_; plast_ = now_; } while (0)
+#else
+#define P_STAMP(slot) do { } while (0)
+#endif
+
 namespace chip {
 
 constexpr int PW = 4;          // blocks (= wavefronts) per workgroup
@@ -35,6 +41,7 @@ struct TranCtl {
   long long nsaved, step;
   long long naccept, nreject, nconvfail, sum_iters, sum_block_iters, n_attempts;
   long long t_cycles_total, t_cycles_barrier;   // wave 0 of workgroup 0: cycles inside the kernel / inside the grid reductions
+  long long stamps[12];                         // diagnostic build (-DCH_STAMPS): shader-clock cycles per phase, wave 0 of workgroup 0
 };
 
 struct PersistArgs {
@@ -52,21 +59,21 @@ struct PersistArgs {
 };
 
 // ---- constants blob layout -------------------------------------------------------------------
-// ints:    [0] n_need  [1] nk  [2] nds  [3] n_pwl  | per needed source {kind, pwl_ofs, pwl_len} | kn_ptr[nk+1] | kn_idx[..] | ds_idx[nds]
-// doubles: per needed source par[8] | kn_coef[..] | pwl_t[n_pwl] | pwl_y[n_pwl]
+// The values a block reads per attempt are the ENTRIES [known-node values | device source values]; entry e = sum of
+// coef * source(t) over its terms (a supply node: one source; a well tied to a supply through a 0 V source: two).
+// ints:    [0] n_need  [1] n_ent  [2] n_pwl  [3] -  | per needed source {kind, pwl_ofs, pwl_len} | ent_ptr[n_ent+1] | ent_idx[..]
+// doubles: per needed source par[8] | ent_coef[..] | pwl_t[n_pwl] | pwl_y[n_pwl]
 struct PConst {
   const int* ci; const double* cd;
   __device__ int n_need() const { return ci[0]; }
-  __device__ int nk() const { return ci[1]; }
-  __device__ int nds() const { return ci[2]; }
-  __device__ int n_pwl() const { return ci[3]; }
+  __device__ int n_ent() const { return ci[1]; }
+  __device__ int n_pwl() const { return ci[2]; }
   __device__ const int* src_rec(int i) const { return ci + 4 + 3 * i; }
-  __device__ const int* kn_ptr() const { return ci + 4 + 3 * n_need(); }
-  __device__ const int* kn_idx() const { return kn_ptr() + nk() + 1; }
-  __device__ const int* ds_idx() const { return kn_idx() + kn_ptr()[nk()]; }
+  __device__ const int* ent_ptr() const { return ci + 4 + 3 * n_need(); }
+  __device__ const int* ent_idx() const { return ent_ptr() + n_ent() + 1; }
   __device__ const double* par(int i) const { return cd + 8 * i; }
-  __device__ const double* kn_coef() const { return cd + 8 * n_need(); }
-  __device__ const double* pwl_t() const { return kn_coef() + kn_ptr()[nk()]; }
+  __device__ const double* ent_coef() const { return cd + 8 * n_need(); }
+  __device__ const double* pwl_t() const { return ent_coef() + ent_ptr()[n_ent()]; }
   __device__ const double* pwl_y() const { return pwl_t() + n_pwl(); }
 };
 
@@ -121,6 +128,35 @@ __device__ inline double p_source(const PConst& C, int i, double t) {
   }
   return 0.0;
 }
+
+// Linear piece of needed source i around time t: on [t_lo, t_hi) the source equals y_lo + (t - t_lo) * slope with the SAME
+// arithmetic as p_pwl (so cached and uncached evaluations agree bit for bit).  Sources that are not piecewise linear in t
+// (pulse with its period wrap, sine) report an empty window and are evaluated in full at every attempt.
+__device__ inline void p_source_piece(const PConst& C, int i, double t, double& t_lo, double& t_hi, double& y_lo, double& slope) {
+  const int* r = C.src_rec(i);
+  const double inf = __builtin_inf();
+  t_lo = inf; t_hi = -inf; y_lo = 0.0; slope = 0.0;
+  if (r[0] == CH_SRC_DC) { t_lo = -inf; t_hi = inf; y_lo = C.par(i)[0]; return; }
+  if (r[0] != CH_SRC_PWL) return;
+  const double* ts = C.pwl_t() + r[1]; const double* ys = C.pwl_y() + r[1];
+  const int n = r[2];
+  if (n == 0) { t_lo = -inf; t_hi = inf; return; }
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (ts[mid] < t) lo = mid + 1; else hi = mid; }
+  int k = lo + 1;
+  if (k <= n && ts[k - 1] == t) ++k;
+  if (k <= 1) { t_lo = -inf; t_hi = ts[0]; y_lo = ys[0]; return; }
+  if (k > n) { t_lo = ts[n - 1]; t_hi = inf; y_lo = ys[n - 1]; return; }
+  const double y0 = ys[k - 2], y1 = ys[k - 1], t0 = ts[k - 2], t1 = ts[k - 1];
+  if (t1 == t0) return;   // zero-width segment: no window
+  t_lo = t0; t_hi = t1;
+  if (y0 == y1) { y_lo = y1; slope = 0.0; } else { y_lo = y0; slope = (y1 - y0) / (t1 - t0); }
+}
+
+// Ordering of one wave's own LDS traffic (cross-lane hand-offs inside the wave): LDS executes a wave's instructions in order,
+// so only the compiler has to be held back.  NOT wave_fence(): a workgroup-scope release also waits for the wave's global
+// stores (vmcnt(0)) — the saved-row stores of an accepted step then stall the next attempt by a memory round trip.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // relaxed agent-scope accesses: global_load/store ... sc1 — L2-coherent hand-off without cache-wide fences
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -199,58 +235,47 @@ __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const d
   return *s_abort == 0;
 }
 
-// (num, den) of one coefficient of the attempt, by lane (all lanes then divide once):
-//   set 0, j = 0..7   BDF: alpha_j (j >= 1); the j = 0 slot is filled afterwards from the reciprocals of set 4
-//   set 1..3, j = 1..7 Lagrange extrapolation weights of the predictors of order k (np points), k-1 (kk points), k+1 (kk+2 points)
-//   set 4, j = 1..5   1 / (tau_0 - tau_j) (summed into alpha_0) ; j = 6: ck, j = 7: ckm1 ; set 5, j = 0: ckp1
-// tau[0] = t_new, tau[1..] = history times (newest first).
-__device__ inline void p_coefficients(const double* tauv, int kk, int np, int nkm1, int nkp1, double hh, double* coef, int lane) {
+// One coefficient of the attempt per lane, all lanes dividing once.  tau0 = the new time (or the dense-output time),
+// tsl[] = history times by ring slot, head = slot of the newest point.  lane = 8*set + j:
+//   set 0, j = 1..kk      BDF coefficients alpha_j   (alpha_0 = sum of the reciprocals of set 4, returned in a0)
+//   set 1..3, j = 1..n    Lagrange extrapolation weights of the predictors of order k (np points), k-1 (kk), k+1 (kk+2)
+//   set 4, j = 1..5       1 / (tau0 - tau_j) ; j = 6: ck = hh / (tau0 - tau_{kk+1}) ; j = 7: ckm1 = hh / (tau0 - tau_kk)
+//   set 5, j = 0          ckp1 = hh / (tau0 - tau_{kk+2})
+// Lanes outside their set's range return 0, so callers sum over all seven history points unconditionally.
+__device__ __forceinline__ double p_coef(double tau0, const double* tsl, int head, int kk, int np, int nkm1, int nkp1, bool lte, double hh, int lane, double& a0) {
   double tau[9];
+  tau[0] = tau0;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) tau[i] = tauv[i];
+  for (int i = 1; i < 9; ++i) tau[i] = tsl[(head - (i - 1)) & 7];
   const int set = lane >> 3, j = lane & 7;
-  double tj = tau[0];
+  const double tj = j == 0 ? tau0 : tsl[(head - (j - 1)) & 7];
+  const int n = set == 0 ? kk : set == 1 ? np : set == 2 ? nkm1 : set == 3 ? nkp1 : 0;
+  const int lo = set == 0 ? 0 : 1;
+  double num = 1.0, den = 1.0;
 #pragma unroll
-  for (int i = 1; i < 8; ++i) tj = (j == i) ? tau[i] : tj;
-  double num = 0.0, den = 1.0;
-  const int n = set == 1 ? np : set == 2 ? nkm1 : set == 3 ? nkp1 : 0;
-  if (set >= 1 && set <= 3 && j >= 1 && j <= n) {
-    num = 1.0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) if (i <= n && i != j) { num *= (tau[0] - tau[i]); den *= (tj - tau[i]); }
-  } else if (set == 0 && j >= 1 && j <= kk) {
-    num = 1.0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) if (i <= kk && i != j) num *= (tau[0] - tau[i]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (i <= kk && i != j) den *= (tj - tau[i]);
-  } else if (set == 4 && j >= 1 && j <= 5) {
-    if (j <= kk) { num = 1.0; den = tau[0] - tj; }
-  } else if (set == 4 && j == 6) {   // ck = hh / (tn - tau[kk+1]) when the error estimate exists
-    double tq = tau[1];
-#pragma unroll
-    for (int i = 2; i < 9; ++i) tq = (kk + 1 == i) ? tau[i] : tq;
-    if (np >= kk + 1) { num = hh; den = tau[0] - tq; }
-  } else if (set == 4 && j == 7) {   // ckm1 = hh / (tn - tau[kk])
-    double tq = tau[1];
-#pragma unroll
-    for (int i = 2; i < 9; ++i) tq = (kk == i) ? tau[i] : tq;
-    if (nkm1 > 0) { num = hh; den = tau[0] - tq; }
-  } else if (set == 5 && j == 0) {   // ckp1 = hh / (tn - tau[kk+2])
-    double tq = tau[1];
-#pragma unroll
-    for (int i = 2; i < 9; ++i) tq = (kk + 2 == i) ? tau[i] : tq;
-    if (nkp1 > 0) { num = hh; den = tau[0] - tq; }
+  for (int i = 0; i < 8; ++i) {
+    const bool in_n = i >= 1 && i <= n && i != j, in_d = i >= lo && i <= n && i != j;
+    num *= in_n ? tau[0] - tau[i] : 1.0;
+    den *= in_d ? tj - tau[i] : 1.0;
   }
+  if (!(set <= 3 && j >= 1 && j <= n)) { num = 0.0; den = 1.0; }
+  // uniform picks of tau_{kk}, tau_{kk+1}, tau_{kk+2}
+  double tk0 = tau[1], tk1 = tau[1], tk2 = tau[1];
+#pragma unroll
+  for (int i = 1; i < 9; ++i) { tk0 = (kk == i) ? tau[i] : tk0; tk1 = (kk + 1 == i) ? tau[i] : tk1; tk2 = (kk + 2 == i) ? tau[i] : tk2; }
+  if (set == 4) {
+    if (j >= 1 && j <= 5) { num = j <= kk ? 1.0 : 0.0; den = tau[0] - tj; }
+    else if (j == 6) { num = lte ? hh : 0.0; den = tau[0] - tk1; }
+    else if (j == 7) { num = nkm1 > 0 ? hh : 0.0; den = tau[0] - tk0; }
+  } else if (set == 5 && j == 0) { num = nkp1 > 0 ? hh : 0.0; den = tau[0] - tk2; }
+  if (num == 0.0) den = 1.0;   // never divide by a history time that is not there
   const double q = num / den;
-  if (lane < 48) coef[lane] = q;
-  wave_fence();
-  if (lane == 0) { double a0 = 0.0; for (int mq = 1; mq <= kk; ++mq) a0 += coef[32 + mq]; coef[0] = a0; }
-  wave_fence();
+  a0 = bcast(row_sum<16>((set == 4 && j >= 1 && j <= 5) ? q : 0.0), 32);
+  return q;
 }
 
 // LDS per workgroup: [consts: cd doubles | ci ints] [part PW*8 | summ 8] [PW wave regions]
-// wave region (doubles): st[ndev*41] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq w qn pm pp x0 dm [11*nc] | Xh[8*nc] | Qh[8*nc] | tauv[10] | coef[48] | asrc[64]
+// wave region (doubles): st[ndev*41] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq w qn pm pp x0 dm [11*nc] | Xh[8*nc] | Qh[8*nc] | tsl[8] | coef[48]
 //                        | kvl[nk] svl[nsrc] | pl[max_mc*B4L_STRIDE] | ints: class blob, MOS class list
 template <int NC>
 __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const PersistArgs p) {
@@ -261,6 +286,9 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
   const long long cyc0 = wall_clock64();
   long long cyc_bar = 0;
+#ifdef CH_STAMPS
+  unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast_ = __builtin_readcyclecounter();
+#endif
   // ---- workgroup-shared constants ----
   double* cdl = lds;
   int* cil = (int*)(cdl + p.n_cd);
@@ -288,8 +316,9 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   double* wv = hq + nc; double* qn = wv + nc; double* pm = qn + nc; double* pp = pm + nc; double* x0l = pp + nc;
   int* dml = (int*)(x0l + nc);
   double* Xh = x0l + 2 * nc; double* Qh = Xh + 8 * nc;
-  double* tauv = Qh + 8 * nc; double* coef = tauv + 10; double* asrc = coef + 48;
-  double* kvl = asrc + P_MAXSRC; double* svl = kvl + a.nk;
+  double* tsl = Qh + 8 * nc; double* coef = tsl + 8;
+  long long* stl = (long long*)(coef + 40);   // statistics counters (lane 0 updates them): they would only crowd the scalar registers
+  double* kvl = coef + 48; double* svl = kvl + a.nk;
   double* pl = svl + a.nsrc;
   int* mptr = (int*)(pl + (size_t)a.max_mc * B4L_STRIDE);
   int* slots = mptr + (nc * nc + 1) + (nc + 1);
@@ -298,7 +327,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   const long sofs = (long)s * a.n_unk + uofs;
   const bool mine = live && lane < nc;
 
-  // ---- once per transient: class blob, BSIM4 columns, flags, history ring ----
+  // ---- once per transient: class blob, BSIM4 columns, flags, history ring; A and C are zeroed once (the register LU never
+  //      writes them back, the gather rewrites every structural non-zero each iteration) ----
   if (live) {
     const int* bsrc = a.blob + cm.blob_ofs;
     for (int i = lane; i < cm.blob_ints; i += 64) mptr[i] = bsrc[i];
@@ -311,6 +341,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       for (int q = 1; q < 8; ++q) cl = (j == q) ? bm.mc[q] : cl;
       pl[j * B4L_STRIDE + i] = a.mosp[((long)cl * a.Smos + scol) * (long)B4I_COUNT + i];
     }
+    for (int i = lane; i < nc * lda + nc * nc; i += 64) A[i] = 0.0;
     if (mine) {
       dml[lane] = a.dmask[uofs + lane] | ((a.unk_obs[uofs + lane] + 1) << 8);
 #pragma unroll
@@ -321,49 +352,65 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       Xh[1 * nc + lane] = 0.0; Qh[1 * nc + lane] = 0.0;   // ring slot 1 = first candidate
     }
   }
+  if (lane < 8) tsl[(8 - lane) & 7] = p.ctl->tslot[lane];   // canonical (newest first) -> ring slots, head = 0
   // ---- controller state (identical in every wave) ----
   double t, h; int k, nhist, steps_at_order, ibp, isave, status = CH_OK, exit_reason = PX_RUNNING;
   bool reset_rate;
-  long long nsaved, step, naccept, nreject, nconvfail, sum_iters, sum_block_iters, n_attempts;
+  int nsaved, step;
+  enum { ST_ACC = 0, ST_REJ, ST_FAIL, ST_ITERS, ST_BITERS, ST_ATT };
   int head = 0;   // ring slot of the newest point; slot (head - j) & 7 holds the j-th newest, (head + 1) & 7 the candidate
   {
     const TranCtl* cs = p.ctl;
     t = cs->t; h = cs->h; k = cs->k; nhist = cs->nhist; steps_at_order = cs->steps_at_order; reset_rate = cs->reset_rate != 0;
-    ibp = cs->ibp; isave = cs->isave; nsaved = cs->nsaved; step = cs->step;
-    naccept = cs->naccept; nreject = cs->nreject; nconvfail = cs->nconvfail; sum_iters = cs->sum_iters; sum_block_iters = cs->sum_block_iters; n_attempts = cs->n_attempts;
-    if (lane < 8) tauv[lane] = 0.0;   // placeholder; history times live in tsl below
+    ibp = cs->ibp; isave = cs->isave; nsaved = (int)cs->nsaved; step = (int)cs->step;
+    if (lane == 0) { stl[ST_ACC] = cs->naccept; stl[ST_REJ] = cs->nreject; stl[ST_FAIL] = cs->nconvfail; stl[ST_ITERS] = cs->sum_iters; stl[ST_BITERS] = cs->sum_block_iters; stl[ST_ATT] = cs->n_attempts; }
   }
-  double tsl[8];   // times by ring slot
-#pragma unroll
-  for (int j = 0; j < 8; ++j) tsl[(8 - j) & 7] = p.ctl->tslot[j];   // canonical (newest first) -> ring slots, head = 0
   double rate_prev = 1.0;
-  wave_fence();
+  lds_fence();
   __syncthreads();
 
   const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar, 300.15};
-  const int n_need = C.n_need(), nkk = C.nk(), nds = C.nds();
+  const int n_ent = C.n_ent();
+  // this lane's entry (a known-node or device-source value): its terms, and the linear piece of up to two of them
+  const int e_p0 = lane < n_ent ? C.ent_ptr()[lane] : 0, e_nt = lane < n_ent ? C.ent_ptr()[lane + 1] - e_p0 : 0;
+  const int e_i0 = e_nt > 0 ? C.ent_idx()[e_p0] : 0, e_i1 = e_nt > 1 ? C.ent_idx()[e_p0 + 1] : 0;
+  const double e_c0 = e_nt > 0 ? C.ent_coef()[e_p0] : 0.0, e_c1 = e_nt > 1 ? C.ent_coef()[e_p0 + 1] : 0.0;
+  double s0_lo = __builtin_inf(), s0_hi = -__builtin_inf(), s0_y = 0.0, s0_m = 0.0, s1_lo = __builtin_inf(), s1_hi = -__builtin_inf(), s1_y = 0.0, s1_m = 0.0;
+  double bp_next = 0.0; int bp_at = -1;        // cached p.bps[ibp]
+  double sv_next = 0.0; int sv_at = -1;        // cached p.saveat[isave]
   const long long row_stride = (long long)p.n_obs * a.S;
+  const int my_ob = mine ? (dml[lane] >> 8) - 1 : -1;
   unsigned gen = 0;
 
   // rows due at t0 (the initial state): the host leaves them to the kernel only when it starts fresh
   if (!p.resume) {
     if (p.n_saveat == 0) {
-      if (mine) { const int ob = (dml[lane] >> 8) - 1; if (ob >= 0) p.out_rows[nsaved * row_stride + (long long)ob * a.S + s] = Xh[lane]; }
+      if (my_ob >= 0) p.out_rows[(long long)nsaved * row_stride + (long long)my_ob * a.S + s] = Xh[lane];
       if (blk == 0 && lane == 0) p.out_times[nsaved] = t;
       ++nsaved;
     } else {
       while (isave < p.n_saveat && p.saveat[isave] <= t) {
-        if (mine) { const int ob = (dml[lane] >> 8) - 1; if (ob >= 0) p.out_rows[nsaved * row_stride + (long long)ob * a.S + s] = Xh[lane]; }
+        if (my_ob >= 0) p.out_rows[(long long)nsaved * row_stride + (long long)my_ob * a.S + s] = Xh[lane];
         if (blk == 0 && lane == 0) p.out_times[nsaved] = p.saveat[isave];
         ++nsaved; ++isave;
       }
     }
   }
 
+  P_STAMP(0);   // set-up
   while (step < p.max_steps && t < p.t1) {
     if (p.n_saveat == 0 && nsaved >= p.max_rows) { exit_reason = PX_ROWS_FULL; break; }
-    while (ibp < p.nbp && p.bps[ibp] <= t * (1 + 1e-15) + 1e-300) ++ibp;
-    const double tb = ibp < p.nbp ? p.bps[ibp] : p.t1;
+    // The lane id of the controller code is made opaque once per attempt: otherwise every lane predicate of the select chains
+    // below (lane == j, set == q, ...) is hoisted out of the time loop as a 64-bit mask in scalar registers — dozens of
+    // pairs that spill, each use then costing two v_readlane instead of the one v_cmp that recomputes it.
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    // next break point: global loads only when the index moves
+    for (;;) {
+      if (bp_at != ibp) { bp_next = ibp < p.nbp ? p.bps[ibp] : p.t1; bp_at = ibp; }
+      if (ibp < p.nbp && bp_next <= t * (1 + 1e-15) + 1e-300) ++ibp; else break;
+    }
+    const double tb = bp_next;
     bool hit_bp = false;
     double tn = t + h;
     if (tn >= tb - 1e-3 * h) { tn = tb; hit_bp = true; }
@@ -373,48 +420,55 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     const bool lte = np >= kk + 1;
     const bool try_up = lte && kk < p.kmax && nh >= kk + 2 && steps_at_order + 1 >= kk + 1;
     const int nkm1 = (lte && kk > 1) ? kk : 0, nkp1 = try_up ? kk + 2 : 0;
-    // history times, newest first
-    if (lane < 9) {
-      double v = tn;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const int sl = (head - j) & 7; double ts = tsl[0];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) ts = (sl == q) ? tsl[q] : ts;
-        v = (lane == j + 1) ? ts : v; }
-      tauv[lane] = v;
-    }
-    wave_fence();
-    p_coefficients(tauv, kk, np, nkm1, nkp1, hh, coef, lane);
-    const double alpha0 = coef[0], ck = coef[32 + 6], ckm1 = coef[32 + 7], ckp1 = coef[40];
-    // sources at t_new (their left limit when the step lands on a break point), then the known-node values
+    double alpha0;
+    const double cq = p_coef(tn, tsl, head, kk, np, nkm1, nkp1, lte, hh, ln, alpha0);
+    const double ck = bcast(cq, 38), ckm1 = bcast(cq, 39), ckp1 = bcast(cq, 40);
+    if (ln < 32) coef[ln] = cq;   // the 26 weights go through LDS: as scalars they would take 52 SGPRs and spill
+    lds_fence();
+    P_STAMP(1);   // break points, BDF / predictor coefficients
+    // entries [known-node values | device source values] at t_new (the sources' left limit when the step lands on a break point)
     {
-      const double ts = hit_bp ? nextafter(tn, -__builtin_inf()) : tn;
-      if (lane < n_need) asrc[lane] = p_source(C, lane, ts);
-      wave_fence();
-      if (lane < nkk) { double v = 0.0; for (int q = C.kn_ptr()[lane]; q < C.kn_ptr()[lane + 1]; ++q) v += C.kn_coef()[q] * asrc[C.kn_idx()[q]]; kvl[lane] = v; }
-      if (lane < nds) svl[lane] = asrc[C.ds_idx()[lane]];
+      const double ts = (hit_bp && tn > 0.0) ? __longlong_as_double(__double_as_longlong(tn) - 1) : (hit_bp ? nextafter(tn, -__builtin_inf()) : tn);
+      if (lane < n_ent) {
+        double v = 0.0;
+        if (e_nt <= 2) {   // the usual case: one or two piecewise-linear sources, their current pieces cached in registers
+          if (e_nt > 0) {
+            if (!(s0_lo <= ts && ts < s0_hi)) p_source_piece(C, e_i0, ts, s0_lo, s0_hi, s0_y, s0_m);
+            const double u = (s0_lo <= ts && ts < s0_hi) ? ((s0_m == 0.0) ? s0_y : s0_y + (ts - s0_lo) * s0_m) : p_source(C, e_i0, ts);
+            v += e_c0 * u;
+          }
+          if (e_nt > 1) {
+            if (!(s1_lo <= ts && ts < s1_hi)) p_source_piece(C, e_i1, ts, s1_lo, s1_hi, s1_y, s1_m);
+            const double u = (s1_lo <= ts && ts < s1_hi) ? ((s1_m == 0.0) ? s1_y : s1_y + (ts - s1_lo) * s1_m) : p_source(C, e_i1, ts);
+            v += e_c1 * u;
+          }
+        } else for (int q = e_p0; q < e_p0 + e_nt; ++q) v += C.ent_coef()[q] * p_source(C, C.ent_idx()[q], ts);
+        kvl[lane] = v;   // kvl and svl are contiguous
+      }
     }
-    // ---- predictor and history term from the ring ----
+    P_STAMP(2);   // source waveforms, known-node values
+    // ---- predictor and history term from the ring (weights straight from the lanes that formed them) ----
     const int cand = (head + 1) & 7;
     double x0 = 0.0;
-    if (mine) {
+    {
       double pr = 0.0, hs = 0.0, m1 = 0.0, p1 = 0.0;
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const int sl = (head - j) & 7;
-        const double xv = Xh[sl * nc + lane];
+        const double xv = mine ? Xh[sl * nc + lane] : 0.0;
         if (j == 0) x0 = xv;
-        pr += (j < np ? coef[8 + j + 1] : 0.0) * xv;
-        m1 += (j < nkm1 ? coef[16 + j + 1] : 0.0) * xv;
-        p1 += (j < nkp1 ? coef[24 + j + 1] : 0.0) * xv;
-        if (j < 5) hs += (j < kk ? coef[j + 1] : 0.0) * Qh[sl * nc + lane];
+        pr = fma(coef[8 + j + 1], xv, pr);
+        m1 = fma(coef[16 + j + 1], xv, m1);
+        p1 = fma(coef[24 + j + 1], xv, p1);
+        if (j < 5) hs = fma(coef[j + 1], mine ? Qh[sl * nc + lane] : 0.0, hs);
       }
-      xp[lane] = pr; xl[lane] = pr; hq[lane] = hs; qn[lane] = 0.0; pm[lane] = m1; pp[lane] = p1;
-      wv[lane] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
-      x0l[lane] = x0;
+      if (mine) {
+        xp[lane] = pr; xl[lane] = pr; hq[lane] = hs; qn[lane] = 0.0; pm[lane] = m1; pp[lane] = p1;
+        wv[lane] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
+      }
     }
-    if (live) for (int i = lane; i < nc * lda + nc * nc; i += 64) A[i] = 0.0;
-    wave_fence();
+    lds_fence();
+    P_STAMP(3);   // predictor
 
     // ---- Newton iteration (the register-LU branch of newton_block_kernel, one wave, no workgroup barriers) ----
     int nstat = 1, iters = 0;
@@ -423,7 +477,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     if (live) {
       for (int it = 0; it <= a.maxit; ++it) {
         if (lane < cm.nslots) { const int sl = slots[lane]; if (sl >= 0) eval_slot<false>(ectx, s, dofs, sl, xl, uofs, kvl, svl, pl, st); }
-        wave_fence();
+        lds_fence();
+        P_STAMP(4);   // device evaluation
         for (int w = lane; w < cm.n_work; w += 64) {
           const int2 itw = wl[w];
           const int p0 = itw.x, pe = p0 + (int)((unsigned)itw.y >> 16), e = itw.y & 0x7fff;
@@ -450,7 +505,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
             Cm[e] = s2;
           }
         }
-        wave_fence();
+        lds_fence();
+        P_STAMP(5);   // gather
         constexpr int NCR = NC;
         double r[NCR + 1], cr[NCR];
 #pragma unroll
@@ -464,7 +520,9 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         else if (it == a.maxit) { stop = true; }
         else {
           double dx = 0.0;
+          P_STAMP(6);   // row loads, residual norm
           const bool ok = lu_solve_regs<NCR>(r, nc, lane, dx);
+          P_STAMP(7);   // LU + triangular solves
           if (!ok) { nstat = 2; stop = true; }
           else {
             const double xn = xi + dx;
@@ -486,11 +544,12 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
             }
           }
         }
-        wave_fence();
+        lds_fence();
+        P_STAMP(8);   // update, charge, convergence test
         if (stop) break;
       }
     }
-    // ---- candidate into the ring, local-error sums ----
+    // ---- candidate into the ring, local-error sums (the block's unknowns sit in the first 16 lanes: DPP row sums) ----
     double e2k = 0.0, e2m = 0.0, e2p = 0.0, ndf = 0.0;
     if (mine) {
       const double xn = xl[lane];
@@ -504,84 +563,84 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         if (nkp1 > 0) { tq = (xn - pp[lane]) * w; e2p = tq * tq; }
       }
     }
-    e2k = wave_sum(e2k); e2m = wave_sum(e2m); e2p = wave_sum(e2p); ndf = wave_sum(ndf);
+    e2k = bcast(row_sum<16>(e2k), 0); e2m = bcast(row_sum<16>(e2m), 0); e2p = bcast(row_sum<16>(e2p), 0); ndf = bcast(row_sum<16>(ndf), 0);
     if (live && nstat == 0) rate_prev = iters >= 2 ? fmin(1.0, fmax(rate_new, 1e-4)) : fmin(1.0, rp * 1.5);
     double rec[P_NREC];
     if (p.red_max) { const double inv = ndf > 0.0 ? 1.0 / ndf : 0.0; rec[0] = e2k * inv; rec[1] = e2m * inv; rec[2] = e2p * inv; }
     else { rec[0] = e2k; rec[1] = e2m; rec[2] = e2p; }
     rec[3] = ndf; rec[4] = (double)iters; rec[5] = (double)iters; rec[6] = (live && nstat != 0) ? 1.0 : 0.0; rec[7] = 0.0;
     if (!live) { for (int q = 0; q < P_NREC; ++q) rec[q] = 0.0; }
-    ++gen; ++n_attempts;
+    ++gen;
+    P_STAMP(9);   // candidate, local-error sums
     const long long cb0 = wall_clock64();
     const bool okr = p_grid_reduce(p, gen, rec, part, summ, &s_abort, wave, lane, wg);
     cyc_bar += wall_clock64() - cb0;
+    P_STAMP(10);  // grid reduction
     if (!okr) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
     const double sA = summ[0], sB = summ[1], sC = summ[2], sN = summ[3], sItMax = summ[4], sItSum = summ[5], sFail = summ[6];
     __syncthreads();   // summ is rewritten by the next reduction
-    double errk = 0.0, errkm1 = 0.0, errkp1 = 0.0;
-    if (p.red_max) { errk = ck * sqrt(sA); errkm1 = ckm1 * sqrt(sB); errkp1 = ckp1 * sqrt(sC); }
-    else if (sN > 0.0) { errk = ck * sqrt(sA / sN); errkm1 = ckm1 * sqrt(sB / sN); errkp1 = ckp1 * sqrt(sC / sN); }
-    sum_block_iters += (long long)sItSum;
-    sum_iters += p.red_max ? (long long)sItSum : (long long)sItMax;
+    // error norms of orders k, k-1, k+1 in lanes 0, 1, 2 (one division and one square root for the three)
+    double errk, errkm1, errkp1;
+    double ev3;
+    {
+      const double sv = ln == 0 ? sA : ln == 1 ? sB : sC, cv = ln == 0 ? ck : ln == 1 ? ckm1 : ckp1;
+      ev3 = p.red_max ? cv * sqrt(sv) : (sN > 0.0 ? cv * sqrt(sv / sN) : 0.0);
+      errk = bcast(ev3, 0); errkm1 = bcast(ev3, 1); errkp1 = bcast(ev3, 2);
+    }
+    if (lane == 0) { stl[ST_ATT] += 1; stl[ST_BITERS] += (long long)sItSum; stl[ST_ITERS] += p.red_max ? (long long)sItSum : (long long)sItMax; }
     // ---- the step controller (same policy as ch_circuit::tran_solve) ----
     if (sFail > 0.0) {
-      ++nconvfail; reset_rate = true;
+      if (lane == 0) stl[ST_FAIL] += 1;
+      reset_rate = true;
       h = hh * 0.25; k = 1; steps_at_order = 0;
       if (nhist > 2) nhist = 2;
+      P_STAMP(11);
       continue;
     }
     if (!lte) errk = 0.0;
     // the three candidate factors (2 err + 1e-4)^(-1/(order+1)) are formed by three lanes at once
     double fk, fm, fp;
     {
-      const double ev = lane == 0 ? errk : lane == 1 ? errkm1 : errkp1;
-      const double ex = lane == 0 ? (double)(kk + 1) : lane == 1 ? (double)kk : (double)(kk + 2);
-      const double fv = exp(-log(2.0 * ev + 1e-4) / ex);
+      const double ev = (ln == 0 && !lte) ? 0.0 : ev3;
+      const double ex = ln == 0 ? (double)(kk + 1) : ln == 1 ? (double)kk : (double)(kk + 2);
+      const double fv = exp(-flog(2.0 * ev + 1e-4) / ex);
       fk = bcast(fv, 0); fm = bcast(fv, 1); fp = bcast(fv, 2);
     }
     if (errk > 1.0) {
-      ++nreject;
+      if (lane == 0) stl[ST_REJ] += 1;
       h = hh * fmin(0.9, fmax(0.25, 0.9 * fk));
       steps_at_order = 0;
+      P_STAMP(11);
       continue;
     }
     // ---- accept ----
-    ++naccept; ++step; reset_rate = false;
+    if (lane == 0) stl[ST_ACC] += 1;
+    ++step; reset_rate = false;
     head = cand;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) tsl[q] = (head == q) ? tn : tsl[q];
+    if (lane == 0) tsl[head] = tn;
+    lds_fence();
     nhist = nhist + 1 < p.kmax + 2 ? nhist + 1 : p.kmax + 2;
     if (p.n_saveat > 0) {
-      while (isave < p.n_saveat && p.saveat[isave] <= tn * (1 + 1e-15)) {
-        const double tsv = p.saveat[isave];
+      for (;;) {
+        if (sv_at != isave) { sv_next = isave < p.n_saveat ? p.saveat[isave] : __builtin_inf(); sv_at = isave; }
+        if (!(isave < p.n_saveat && sv_next <= tn * (1 + 1e-15))) break;
+        const double tsv = sv_next;
         const int msv = (kk < nh ? kk : nh) + 1;
         // interpolation weights through the msv newest points (the accepted one included)
-        if (lane < 9) {
-          double v = tsv;
+        double dummy;
+        const double wq = p_coef(tsv, tsl, head, 0, msv, 0, 0, false, 0.0, ln, dummy);
+        if (ln < 32) coef[ln] = wq;
+        lds_fence();
+        double v = 0.0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { const int sl = (head - j) & 7; double ts = tsl[0];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) ts = (sl == q) ? tsl[q] : ts;
-            v = (lane == j + 1) ? ts : v; }
-          tauv[lane] = v;
-        }
-        wave_fence();
-        p_coefficients(tauv, 0, msv, 0, 0, 0.0, coef, lane);
-        if (mine) {
-          const int ob = (dml[lane] >> 8) - 1;
-          if (ob >= 0) {
-            double v = 0.0;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) if (j < msv) v += coef[8 + j + 1] * Xh[((head - j) & 7) * nc + lane];
-            p.out_rows[nsaved * row_stride + (long long)ob * a.S + s] = v;
-          }
-        }
+        for (int j = 0; j < 7; ++j) v = fma(coef[8 + j + 1], mine ? Xh[((head - j) & 7) * nc + lane] : 0.0, v);
+        lds_fence();
+        if (my_ob >= 0) p.out_rows[(long long)nsaved * row_stride + (long long)my_ob * a.S + s] = v;
         if (blk == 0 && lane == 0) p.out_times[nsaved] = tsv;
         ++nsaved; ++isave;
-        wave_fence();
       }
     } else {
-      if (mine) { const int ob = (dml[lane] >> 8) - 1; if (ob >= 0) p.out_rows[nsaved * row_stride + (long long)ob * a.S + s] = Xh[head * nc + lane]; }
+      if (my_ob >= 0) p.out_rows[(long long)nsaved * row_stride + (long long)my_ob * a.S + s] = Xh[head * nc + lane];
       if (blk == 0 && lane == 0) p.out_times[nsaved] = tn;
       ++nsaved;
     }
@@ -603,6 +662,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       for (int b = ibp; b < p.nbp; ++b) if (p.bps[b] > t * (1 + 1e-15)) { nb = p.bps[b]; break; }
       h = fmax(p.dtmin * 10, fmin(h, (nb - t) / 50.0) * p.first_frac);
     }
+    P_STAMP(11);  // controller, saved rows
   }
   if (exit_reason == PX_RUNNING) {
     exit_reason = PX_DONE;
@@ -621,13 +681,12 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     TranCtl* cs = p.ctl;
     cs->t = t; cs->h = h; cs->k = k; cs->nhist = nhist; cs->steps_at_order = steps_at_order; cs->reset_rate = reset_rate ? 1 : 0;
     cs->ibp = ibp; cs->isave = isave; cs->status = status; cs->exit_reason = exit_reason; cs->nsaved = nsaved; cs->step = step;
-    cs->naccept = naccept; cs->nreject = nreject; cs->nconvfail = nconvfail; cs->sum_iters = sum_iters; cs->sum_block_iters = sum_block_iters; cs->n_attempts = n_attempts;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const int sl = (head - j) & 7; double ts = tsl[0];
-#pragma unroll
-      for (int q = 1; q < 8; ++q) ts = (sl == q) ? tsl[q] : ts;
-      cs->tslot[j] = ts; }
+    cs->naccept = stl[ST_ACC]; cs->nreject = stl[ST_REJ]; cs->nconvfail = stl[ST_FAIL]; cs->sum_iters = stl[ST_ITERS]; cs->sum_block_iters = stl[ST_BITERS]; cs->n_attempts = stl[ST_ATT];
+    for (int j = 0; j < 8; ++j) cs->tslot[j] = tsl[(head - j) & 7];
     cs->t_cycles_total = wall_clock64() - cyc0; cs->t_cycles_barrier = cyc_bar;
+#ifdef CH_STAMPS
+    for (int q = 0; q < 12; ++q) cs->stamps[q] = (long long)pacc_[q];
+#endif
   }
 }
 
