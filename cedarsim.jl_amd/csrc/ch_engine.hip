@@ -1044,7 +1044,9 @@ struct ch_circuit {
       for (int v : ci) if (v < 0) { set_err("internal: a needed source is missing from the evaluation list"); return CH_ERR_INTERNAL; }
     }
     const size_t wave_d = persist_wave_doubles();
-    const size_t lds = (cd.size() + (ci.size() + 1) / 2 + PW * P_NREC + P_NREC + PW * wave_d) * sizeof(double);
+    const size_t lds = (cd.size() + (ci.size() + 1) / 2 + PW * P_NREC + P_NREC + 4 + PW * wave_d) * sizeof(double);
+    // wave pairs share the device evaluation by function when every block has the same class and at most 32 evaluation slots
+    const bool pair = A.classes.size() == 1 && h_cms[0].nslots <= 32 && std::getenv("CEDARHIP_PERSIST_NOPAIR") == nullptr;
     if (lds > 150 * 1024) { set_err("device-resident stepper: the workgroup's LDS footprint exceeds 150 KB"); return CH_OK; }
     // ---- output rows ----
     const size_t row_d = std::max<size_t>(1, (size_t)n_obs * S);
@@ -1066,13 +1068,15 @@ struct ch_circuit {
     pa.out_times = d_ptimes.p; pa.out_rows = d_prows.p; pa.max_rows = max_rows; pa.n_obs = n_obs;
     pa.ctl = d_pctl.p; pa.wg_rec = d_wgrec.p; pa.grp_rec = d_grprec.p; pa.counters = d_pcnt.p;
     pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz
+    pa.pair_dbg = std::getenv("CEDARHIP_PAIR_DBG") ? std::atoi(std::getenv("CEDARHIP_PAIR_DBG")) : 0;
     // initial controller state (same first step as the host stepper)
     TranCtl cs; std::memset(&cs, 0, sizeof(cs));
     const double span = t1 - t0;
     double h = o.dt0 > 0 ? o.dt0 : std::min(dtmax, 1e-3 * span);
     h = std::max(10 * dtmin, std::min(h, (bps[0] - t0) / 50.0) * 1e-3);
     cs.t = t0; cs.h = h; cs.k = 1; cs.nhist = 1; cs.reset_rate = 1; cs.tslot[0] = t0;
-    const void* fn = lu_variant == 8 ? (const void*)tran_persistent_kernel<8> : lu_variant == 12 ? (const void*)tran_persistent_kernel<12> : (const void*)tran_persistent_kernel<16>;
+    const void* fn = lu_variant <= 12 ? (pair ? (const void*)tran_persistent_kernel<12, true> : (const void*)tran_persistent_kernel<12, false>)
+                                      : (pair ? (const void*)tran_persistent_kernel<16, true> : (const void*)tran_persistent_kernel<16, false>);
     {
       hipFuncAttributes fa;
       HIPCHK(hipFuncGetAttributes(&fa, fn));

@@ -145,6 +145,50 @@ __device__ __forceinline__ void widen_stamp(const double* t, double* st) {
   }
 }
 
+// Linear devices (R, C, L, V, I, VCVS, VCCS; src/simpledevices.jl:49-373) into a narrow 40-double record.
+__device__ __forceinline__ void eval_linear(const EvalCtx& a, int kind, int d, long pi, double m, const double (&v)[4], const double* svl, double* st) {
+  switch (kind) {
+    case K_R: {
+      const double g = m / a.dpar[pi], i = g * (v[0] - v[1]);
+      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
+      st[8] = g; st[9] = -g; st[12] = -g; st[13] = g;
+      st[24] = 0.0; st[25] = 0.0; st[28] = 0.0; st[29] = 0.0;
+    } break;
+    case K_C: {
+      const double c = m * a.dpar[pi], q = c * (v[0] - v[1]);
+      st[0] = 0.0; st[1] = 0.0; st[4] = q; st[5] = -q;
+      st[8] = 0.0; st[9] = 0.0; st[12] = 0.0; st[13] = 0.0;
+      st[24] = c; st[25] = -c; st[28] = -c; st[29] = c;
+    } break;
+    case K_I: {
+      const double i = m * svl[a.dsrc[d]];
+      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
+    } break;
+    case K_V: case K_L: case K_VCVS_A: {
+      // terminals (a, b, branch): KCL rows get ±m·i, branch row: va - vb - V(t) [- d/dt(L i)]
+      const double ib = v[2];
+      const double src = kind == K_V ? svl[a.dsrc[d]] : 0.0;
+      const double l = kind == K_L ? a.dpar[pi] : 0.0;
+      st[0] = m * ib; st[1] = -m * ib; st[2] = v[0] - v[1] - src;
+      st[4] = 0.0; st[5] = 0.0; st[6] = -l * ib;
+      st[8 + 2] = m; st[8 + 6] = -m; st[8 + 8] = 1.0; st[8 + 9] = -1.0; st[8 + 10] = 0.0;
+      st[24 + 2] = 0.0; st[24 + 6] = 0.0; st[24 + 8] = 0.0; st[24 + 9] = 0.0; st[24 + 10] = -l;
+    } break;
+    case K_VCVS_B: {
+      // terminals (branch, c, d): branch row gets -gain·(vc - vd)
+      const double g = a.dpar[pi];
+      st[0] = -g * (v[1] - v[2]); st[4] = 0.0;
+      st[8 + 1] = -g; st[8 + 2] = g; st[24 + 1] = 0.0; st[24 + 2] = 0.0;
+    } break;
+    case K_VCCS: {
+      const double g = m * a.dpar[pi], i = g * (v[2] - v[3]);
+      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
+      st[8 + 2] = g; st[8 + 3] = -g; st[8 + 6] = -g; st[8 + 7] = g;
+      st[24 + 2] = 0.0; st[24 + 3] = 0.0; st[24 + 6] = 0.0; st[24 + 7] = 0.0;
+    } break;
+  }
+}
+
 // Evaluate one lane slot of the device-evaluation phase.  slot = (local device << 4) | (first << 3) | direction:
 // compiled Verilog-A devices take one lane per unknown terminal (direction-parallel duals), every other device one lane.
 template <bool WIDE>
@@ -186,47 +230,48 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
     if (WIDE) widen_stamp(st, st_final);
     return;
   }
-  switch (kind) {
-    case K_R: {
-      const double g = m / a.dpar[pi], i = g * (v[0] - v[1]);
-      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
-      st[8] = g; st[9] = -g; st[12] = -g; st[13] = g;
-      st[24] = 0.0; st[25] = 0.0; st[28] = 0.0; st[29] = 0.0;
-    } break;
-    case K_C: {
-      const double c = m * a.dpar[pi], q = c * (v[0] - v[1]);
-      st[0] = 0.0; st[1] = 0.0; st[4] = q; st[5] = -q;
-      st[8] = 0.0; st[9] = 0.0; st[12] = 0.0; st[13] = 0.0;
-      st[24] = c; st[25] = -c; st[28] = -c; st[29] = c;
-    } break;
-    case K_I: {
-      const double i = m * svl[a.dsrc[d]];
-      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
-    } break;
-    case K_V: case K_L: case K_VCVS_A: {
-      // terminals (a, b, branch): KCL rows get ±m·i, branch row: va - vb - V(t) [- d/dt(L i)]
-      const double ib = v[2];
-      const double src = kind == K_V ? svl[a.dsrc[d]] : 0.0;
-      const double l = kind == K_L ? a.dpar[pi] : 0.0;
-      st[0] = m * ib; st[1] = -m * ib; st[2] = v[0] - v[1] - src;
-      st[4] = 0.0; st[5] = 0.0; st[6] = -l * ib;
-      st[8 + 2] = m; st[8 + 6] = -m; st[8 + 8] = 1.0; st[8 + 9] = -1.0; st[8 + 10] = 0.0;
-      st[24 + 2] = 0.0; st[24 + 6] = 0.0; st[24 + 8] = 0.0; st[24 + 9] = 0.0; st[24 + 10] = -l;
-    } break;
-    case K_VCVS_B: {
-      // terminals (branch, c, d): branch row gets -gain·(vc - vd)
-      const double g = a.dpar[pi];
-      st[0] = -g * (v[1] - v[2]); st[4] = 0.0;
-      st[8 + 1] = -g; st[8 + 2] = g; st[24 + 1] = 0.0; st[24 + 2] = 0.0;
-    } break;
-    case K_VCCS: {
-      const double g = m * a.dpar[pi], i = g * (v[2] - v[3]);
-      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
-      st[8 + 2] = g; st[8 + 3] = -g; st[8 + 6] = -g; st[8 + 7] = g;
-      st[24 + 2] = 0.0; st[24 + 3] = 0.0; st[24 + 6] = 0.0; st[24 + 7] = 0.0;
-    } break;
-  }
+  eval_linear(a, kind, d, pi, m, v, svl, st);
   if (WIDE) widen_stamp(st, st_final);
+}
+
+// One HALF of a narrow slot's evaluation, for the wave pairs of the device-resident stepper (ch_persist.hpp): a BSIM4
+// instance is split by FUNCTION — PART 0 = threshold / mobility / drain current / output resistance / substrate and junction
+// currents (the I and G entries of the record), PART 1 = the same threshold front end, then the capMod-2 intrinsic charges,
+// junction and overlap charges (Q and C entries).  The value path dominates the model (r01_notes: 3 -> 1 derivative directions
+// removes 1 000 of 6 300 instructions), so the split is along outputs, not along derivative directions: the compiler drops
+// what a half does not store (3 925 and 3 395 instructions against 6 289).  Linear devices are evaluated whole by PART 0.
+template <int PART>
+__device__ __forceinline__ void eval_slot_part(const EvalCtx a, int s, int dofs, int slot, const double* xl, int uofs,
+                                               const double* kvl, const double* svl, const double* pl, double* stage) {
+  const int dl = slot >> 4;
+  const int d = dofs + dl;
+  double* st = stage + (size_t)dl * StampLayout<false>::STRIDE;
+  const int kind = a.dkind[d];
+  if (PART == 1 && kind != K_MOS) return;
+  const int* tm = a.dterm + NTERM * d;
+  double v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int t = tm[k]; v[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
+  const long pi = (long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0);
+  const double m = a.dmult[pi];
+  if (kind == K_MOS) {
+    const B4Col P{pl + (size_t)a.dcls_local[d] * B4L_STRIDE};
+    double o[40];
+    b4_device(P, v[0], v[1], v[2], v[3], a.gmin, o);
+    if (PART == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st[j] = m * o[j];
+#pragma unroll
+      for (int j = 8; j < 24; ++j) st[j] = m * o[j];
+    } else {
+#pragma unroll
+      for (int j = 4; j < 8; ++j) st[j] = m * o[j];
+#pragma unroll
+      for (int j = 24; j < 40; ++j) st[j] = m * o[j];
+    }
+    return;
+  }
+  eval_linear(a, kind, d, pi, m, v, svl, st);
 }
 
 // ---- DPP reductions over the 16-lane rows of a wavefront (no LDS round trip, ~8 cycles a step) ----

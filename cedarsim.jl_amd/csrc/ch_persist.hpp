@@ -56,6 +56,7 @@ struct PersistArgs {
   TranCtl* ctl; int resume;
   double* wg_rec; double* grp_rec; unsigned* counters;   // grid reduction: [n_wg][8], [8][8], 10 counters on 128-byte lines
   long long spin_ticks;       // bound of every spin, in wall_clock64 ticks (100 MHz)
+  int pair_dbg;               // diagnostic: 1 = the first wave of a pair evaluates both halves itself (A/B of the function split)
 };
 
 // ---- constants blob layout -------------------------------------------------------------------
@@ -277,7 +278,13 @@ __device__ __forceinline__ double p_coef(double tau0, const double* tsl, int hea
 // LDS per workgroup: [consts: cd doubles | ci ints] [part PW*8 | summ 8] [PW wave regions]
 // wave region (doubles): st[ndev*41] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq w qn pm pp x0 dm [11*nc] | Xh[8*nc] | Qh[8*nc] | tsl[8] | coef[48]
 //                        | kvl[nk] svl[nsrc] | pl[max_mc*B4L_STRIDE] | ints: class blob, MOS class list
-template <int NC>
+// PAIR: the two waves of a pair (2q, 2q+1) share the device evaluation of their two blocks BY FUNCTION (eval_slot_part): wave
+// 2q evaluates the current half (I, G) of every MOSFET of both blocks plus the linear devices, wave 2q+1 the charge half (Q, C);
+// each wave then gathers, factors and updates its OWN block.  The device evaluation — 45 of the 100 thousand cycles of an
+// attempt — shrinks to its longer half, with one wave per SIMD as before.  The pair meets twice per Newton iteration through
+// two counters in LDS (in-order LDS pipeline: a wave's stamp writes precede its counter write).  Requires one block class and
+// at most 32 evaluation slots per block.
+template <int NC, bool PAIR>
 __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const PersistArgs p) {
   typedef StampLayout<false> SL;
   extern __shared__ double lds[];
@@ -294,10 +301,12 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   int* cil = (int*)(cdl + p.n_cd);
   double* part = cdl + p.n_cd + ((p.n_ci + 1) >> 1);
   double* summ = part + PW * P_NREC;
-  double* W = summ + P_NREC + (size_t)wave * p.wave_doubles;
+  int* pfl = (int*)(summ + P_NREC);   // per pair: {sequence of wave 2q, of wave 2q+1, done flag of block 2q, of block 2q+1}
+  double* W = summ + P_NREC + 4 + (size_t)wave * p.wave_doubles;
   for (int i = tid; i < p.n_cd; i += PW * 64) cdl[i] = p.cd[i];
   for (int i = tid; i < p.n_ci; i += PW * 64) cil[i] = p.ci[i];
   if (tid == 0) s_abort = 0;
+  if (tid < 8) pfl[tid] = 0;
   __syncthreads();
   const PConst C{cil, cdl};
 
@@ -326,6 +335,30 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   const int2* wl = (const int2*)(mptr + cm.wl_ofs);
   const long sofs = (long)s * a.n_unk + uofs;
   const bool mine = live && lane < nc;
+  // paired evaluation: lanes 0..31 work on the pair's first block, lanes 32..63 on its second
+  const int role = wave & 1, pairq = wave >> 1, half = lane >> 5;
+  int* pf = pfl + pairq * 4;
+  const int blk_h = wg * PW + (wave & ~1) + half;
+  const bool live_h = PAIR && blk_h < p.nblk;
+  const int bqh = live_h ? blk_h : 0, c_h = bqh / a.S, s_h = bqh - c_h * a.S;
+  const int uofs_h = PAIR ? a.bmeta[c_h].uofs : uofs, dofs_h = PAIR ? a.bmeta[c_h].dofs : dofs;
+  double* Wh = summ + P_NREC + 4 + (size_t)((wave & ~1) + half) * p.wave_doubles;   // region of this lane's block (same class, same layout)
+  double* st_h = Wh; double* xl_h = Wh + (xl - W); double* pl_h = Wh + (pl - W);
+  // the slot table too comes from the region of the lane's block: a wave without a block of its own (odd block count, single
+  // circuit) has staged nothing into its own region and only helps its partner
+  const int* slots_h = (const int*)((const char*)slots + ((const char*)Wh - (const char*)W));
+  int pseq = 0; bool pair_broken = false;
+  auto pair_sync = [&]() {   // both waves of the pair arrive; bounded like every other wait of this kernel
+    ++pseq;
+    lds_fence();
+    if (lane == 0) __hip_atomic_store(pf + role, pseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const long long t0w = wall_clock64();
+    while (__hip_atomic_load(pf + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pseq) {
+      if (wall_clock64() - t0w > p.spin_ticks) { pair_broken = true; break; }
+      __builtin_amdgcn_s_sleep(0);
+    }
+    lds_fence();
+  };
 
   // ---- once per transient: class blob, BSIM4 columns, flags, history ring; A and C are zeroed once (the register LU never
   //      writes them back, the gather rewrites every structural non-zero each iteration) ----
@@ -346,8 +379,9 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       dml[lane] = a.dmask[uofs + lane] | ((a.unk_obs[uofs + lane] + 1) << 8);
 #pragma unroll
       for (int j = 0; j < 7; ++j) {   // global slot j holds the j-th newest point (canonical order); with head = 0 that is ring slot (-j) & 7
-        Xh[((8 - j) & 7) * nc + lane] = a.X[(long)j * a.slot_stride + sofs + lane];
-        Qh[((8 - j) & 7) * nc + lane] = a.Qh[(long)j * a.slot_stride + sofs + lane];
+        const bool have = j < p.ctl->nhist;   // slots beyond the history are left over from earlier solves
+        Xh[((8 - j) & 7) * nc + lane] = have ? a.X[(long)j * a.slot_stride + sofs + lane] : 0.0;
+        Qh[((8 - j) & 7) * nc + lane] = have ? a.Qh[(long)j * a.slot_stride + sofs + lane] : 0.0;
       }
       Xh[1 * nc + lane] = 0.0; Qh[1 * nc + lane] = 0.0;   // ring slot 1 = first candidate
     }
@@ -370,6 +404,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   __syncthreads();
 
   const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar, 300.15};
+  EvalCtx ectx_h = ectx;   // the lane's block may belong to another sample than the wave's own
+  ectx_h.gmin = a.gmin_s[a.Sgmin > 1 ? s_h : 0];
   const int n_ent = C.n_ent();
   // this lane's entry (a known-node or device-source value): its terms, and the linear piece of up to two of them
   const int e_p0 = lane < n_ent ? C.ent_ptr()[lane] : 0, e_nt = lane < n_ent ? C.ent_ptr()[lane + 1] - e_p0 : 0;
@@ -455,12 +491,12 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const int sl = (head - j) & 7;
-        const double xv = mine ? Xh[sl * nc + lane] : 0.0;
+        const double xv = (mine && j < nh) ? Xh[sl * nc + lane] : 0.0;   // points beyond the history in use may hold anything (0 * NaN)
         if (j == 0) x0 = xv;
         pr = fma(coef[8 + j + 1], xv, pr);
         m1 = fma(coef[16 + j + 1], xv, m1);
         p1 = fma(coef[24 + j + 1], xv, p1);
-        if (j < 5) hs = fma(coef[j + 1], mine ? Qh[sl * nc + lane] : 0.0, hs);
+        if (j < 5) hs = fma(coef[j + 1], (mine && j < kk) ? Qh[sl * nc + lane] : 0.0, hs);
       }
       if (mine) {
         xp[lane] = pr; xl[lane] = pr; hq[lane] = hs; qn[lane] = 0.0; pm[lane] = m1; pp[lane] = p1;
@@ -474,11 +510,31 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     int nstat = 1, iters = 0;
     double rate_new = -1.0, dn_prev = 0.0;
     const double rp = reset_rate ? 1.0 : rate_prev;
-    if (live) {
-      for (int it = 0; it <= a.maxit; ++it) {
+    bool done_own = !live;
+    if (live || PAIR) {
+      for (int it = 0; PAIR || it <= a.maxit; ++it) {
+        if (PAIR) {
+          if (lane == 0) pf[2 + role] = done_own ? 1 : 0;
+          pair_sync();                                   // both iterates (or their done flags) are in LDS
+          const int d0 = pf[2], d1 = pf[3];
+          if ((d0 && d1) || pair_broken) break;
+          const int sq = lane & 31;
+          if (live_h && !(half ? d1 : d0) && sq < cm.nslots) {
+            const int sl = slots_h[sq];
+            if (sl >= 0) {
+              if (role == 0) eval_slot_part<0>(ectx_h, s_h, dofs_h, sl, xl_h, uofs_h, kvl, svl, pl_h, st_h);
+              if (role == 1 ? (p.pair_dbg & 1) == 0 : (p.pair_dbg & 1) == 1) eval_slot_part<1>(ectx_h, s_h, dofs_h, sl, xl_h, uofs_h, kvl, svl, pl_h, st_h);
+            }
+          }
+          pair_sync();                                   // both halves of every stamp record are in LDS
+          P_STAMP(4);   // device evaluation (one half of it)
+          if (pair_broken) break;
+          if (done_own) continue;
+        } else {
         if (lane < cm.nslots) { const int sl = slots[lane]; if (sl >= 0) eval_slot<false>(ectx, s, dofs, sl, xl, uofs, kvl, svl, pl, st); }
         lds_fence();
         P_STAMP(4);   // device evaluation
+        }
         for (int w = lane; w < cm.n_work; w += 64) {
           const int2 itw = wl[w];
           const int p0 = itw.x, pe = p0 + (int)((unsigned)itw.y >> 16), e = itw.y & 0x7fff;
@@ -546,7 +602,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         }
         lds_fence();
         P_STAMP(8);   // update, charge, convergence test
-        if (stop) break;
+        if (stop) { if (PAIR) done_own = true; else break; }
       }
     }
     // ---- candidate into the ring, local-error sums (the block's unknowns sit in the first 16 lanes: DPP row sums) ----
@@ -570,13 +626,14 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     else { rec[0] = e2k; rec[1] = e2m; rec[2] = e2p; }
     rec[3] = ndf; rec[4] = (double)iters; rec[5] = (double)iters; rec[6] = (live && nstat != 0) ? 1.0 : 0.0; rec[7] = 0.0;
     if (!live) { for (int q = 0; q < P_NREC; ++q) rec[q] = 0.0; }
+    if (pair_broken) rec[7] = 1.0;   // a pair wait ran into its bound: every wave of the grid leaves at this attempt
     ++gen;
     P_STAMP(9);   // candidate, local-error sums
     const long long cb0 = wall_clock64();
     const bool okr = p_grid_reduce(p, gen, rec, part, summ, &s_abort, wave, lane, wg);
     cyc_bar += wall_clock64() - cb0;
     P_STAMP(10);  // grid reduction
-    if (!okr) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
+    if (!okr || summ[7] != 0.0) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
     const double sA = summ[0], sB = summ[1], sC = summ[2], sN = summ[3], sItMax = summ[4], sItSum = summ[5], sFail = summ[6];
     __syncthreads();   // summ is rewritten by the next reduction
     // error norms of orders k, k-1, k+1 in lanes 0, 1, 2 (one division and one square root for the three)
@@ -633,7 +690,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         lds_fence();
         double v = 0.0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) v = fma(coef[8 + j + 1], mine ? Xh[((head - j) & 7) * nc + lane] : 0.0, v);
+        for (int j = 0; j < 7; ++j) v = fma(coef[8 + j + 1], (mine && j < msv) ? Xh[((head - j) & 7) * nc + lane] : 0.0, v);
         lds_fence();
         if (my_ob >= 0) p.out_rows[(long long)nsaved * row_stride + (long long)my_ob * a.S + s] = v;
         if (blk == 0 && lane == 0) p.out_times[nsaved] = tsv;
