@@ -38,11 +38,13 @@ def algorithmic_bytes_per_block_iteration(nc, n_mos):
 
 def _oracle_worker(args):
     """One host thread: full transients of one decoupled DFF tile until the deadline (ctypes releases the GIL)."""
-    deadline, max_reps = args
+    deadline, max_reps = args[0], args[1]
+    proxy = len(args) > 2 and args[2]
     from oracle_binding import Oracle
     from cedarsim_jl_amd import dc_opts, tran_opts
     from cedarsim_jl_amd.workloads import DFF_TSPAN, dff_array
     o = Oracle(dff_array(1))
+    o.set_proxy(proxy)
     iters = reps = 0
     while True:
         rc, t, v, xf, st = o.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=TOL, reltol=TOL, dc=dc_opts(abstol=1e-14)))
@@ -54,7 +56,7 @@ def _oracle_worker(args):
     return iters, reps
 
 
-def cpu_baseline(seconds_single=5.0, seconds_multi=10.0):
+def cpu_baseline(seconds_single=5.0, seconds_multi=10.0, seconds_proxy=5.0):
     """Oracle ("port") timed on the host cores on a bounded sample: full transients of single decoupled tiles
     (1 of the 1024), first on one core, then one tile per thread on every core this process may use;
     converted to array-level iterations/s by dividing the tile rate by the tile count."""
@@ -74,7 +76,17 @@ def cpu_baseline(seconds_single=5.0, seconds_multi=10.0):
     elm = time.perf_counter() - t0
     itm, repsm = sum(r[0] for r in res), sum(r[1] for r in res)
     tile_rate_1, tile_rate_m = it1 / el1, itm / elm
-    return {"value": tile_rate_m / N_TILES, "unit": "newton_iters/s (1024-DFF array equivalent)", "cores": cores, "kind": "port",
+    # B0: "reference-like" cost proxy on one core — finite-difference Jacobian from n+1 residuals, reused like
+    # IDA's modified Newton (src/dcop.jl:28,53-94; benchmarks/gf180_dff_solver_bench.jl:60-81), one tile, scaled by the tile
+    # count.  Flattering to the reference: its dense LU is O(n^3) of the WHOLE 13.3k system, here it is 25x25 per tile.
+    t0 = time.perf_counter()
+    itp, repsp = _oracle_worker((t0 + seconds_proxy, 200, True))
+    elp = time.perf_counter() - t0
+    proxy = {"kind": "proxy, not CedarSim", "value": itp / elp / N_TILES, "unit": "newton_iters/s (1024-DFF array equivalent)", "cores": 1,
+             "seconds_per_tile_transient": elp / repsp, "seconds_per_array_transient_scaled": elp / repsp * N_TILES,
+             "sample": "%d full transients of one decoupled tile with a finite-difference Jacobian (26 residuals each) reused across "
+                       "iterations and steps, %.1f s" % (repsp, elp)}
+    return {"value": tile_rate_m / N_TILES, "reference_like_proxy_B0": proxy, "unit": "newton_iters/s (1024-DFF array equivalent)", "cores": cores, "kind": "port",
             "sample": "%d full transients of single decoupled DFF tiles (1 of the %d; dense-LU MNA oracle, n=25) on %d threads, "
                       "%.1f s; tile rate %.0f iters/s divided by %d" % (repsm, N_TILES, cores, elm, tile_rate_m, N_TILES),
             "single_core_value": tile_rate_1 / N_TILES, "seconds_per_tile_transient_single_core": el1 / reps1}
@@ -87,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tiles", type=int, default=N_TILES, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-skew", action="store_true", help="skip the second, clearly labelled measurement with per-tile clock skew")
+    ap.add_argument("--stepper", default="auto", choices=["auto", "host", "device"], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import numpy as np
@@ -131,9 +145,9 @@ def main():
         eng.set_samples(1)
         eng.set_params(slots, vals)
     info = eng.info()
-    opts = tran_opts(abstol=TOL, reltol=TOL, dc=dc_opts(abstol=1e-14))
+    opts = tran_opts(abstol=TOL, reltol=TOL, dc=dc_opts(abstol=1e-14), stepper=args.stepper)
 
-    def one_transient():
+    def one_transient(eng=eng):
         rc, t, v, xf, st = eng.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
         if rc != 0:
             raise SystemExit("transient failed: rc=%d %s" % (rc, ctx.last_error()))
@@ -150,19 +164,23 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    iters = block_iters = launches = 0
-    dev_s = dc_s = 0.0
+    iters = block_iters = launches = attempts = 0
+    dev_s = dc_s = bar_s = 0.0
     naccept = nreject = 0
     q = None
+    stepper_used = 0
     for _ in range(args.steps):
         st, q = one_transient()
         iters += st["nnonliniter"]
-        block_iters += st["n_block_iters"]
-        launches += st["n_kernel_launches"]
-        dev_s += st["device_seconds"]
+        block_iters += st["step_block_iters"]          # inside the time-stepping kernel(s): what the roofline line is about
+        launches += st["step_kernel_launches"]
+        dev_s += st["step_kernel_seconds"]
         dc_s += st["dc_seconds"]
+        bar_s += st["barrier_seconds"]
+        attempts += st["n_step_attempts"]
         naccept += st["naccept"]
         nreject += st["nreject"]
+        stepper_used = st["stepper"]
     barrier()
     el = time.perf_counter() - t0
 
@@ -187,15 +205,22 @@ def main():
         avg_launch = dev_s / max(1, launches)
         bytes_per_launch = bpi * block_iters / max(1, launches)
         achieved = bytes_per_launch / avg_launch / 1e9 if avg_launch > 0 else 0.0
+        # HBM traffic and the fp64 instruction mix come from separate rocprofv3 --pmc passes (scripts/profile_round.sh); they
+        # are quoted only when that file was measured on THIS build of the library (hash of the .so) and this stepper
         traffic = flops = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
+        pmc_note = "no PMC file for this build"
+        import hashlib
+        from cedarsim_jl_amd import engine as _eng
+        lib_hash = hashlib.sha256(open(_eng.LIB_PATH, "rb").read()).hexdigest()
+        for cand in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")):
             try:
-                pj = json.load(open(pmc))
+                pj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            except Exception:  # noqa: BLE001
+                continue
+            if pj.get("lib_sha256") == lib_hash and pj.get("tiles", N_TILES) == args.tiles:
                 traffic = pj.get("hbm_bytes_per_launch")
                 flops = pj.get("fp64_flop_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+                pmc_note = "profiles/%s (same library build, sha256 %s...)" % (cand, lib_hash[:12])
         try:
             triad, fp64_peak = ctx.triad_gbps(), ctx.fp64_tflops()
         except RuntimeError:
@@ -212,9 +237,15 @@ def main():
                        "tile_newton_iters_per_sec": tot_iters * args.tiles / max_el,
                        "accepted_steps": naccept // max(1, args.steps), "rejected_steps": nreject // max(1, args.steps),
                        "reference_gate_q": all_q[0], "reference_gate_ok": gate_ok,
+                       "step_controller": "device-resident (one persistent cooperative launch per transient)" if stepper_used == 2 else "host (one launch per attempt)",
                        "multi_gpu": "independent process-variation samples per rank; all_gather of results only"},
-            "roofline": {"bound": "hbm", "kernel": "newton_block_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": "tran_persistent_kernel (one launch per transient)" if stepper_used == 2 else "newton_block_kernel (one launch per step attempt)",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": pmc_note,
+                         "measured_hbm_gbps": (traffic / avg_launch / 1e9) if (traffic and avg_launch > 0) else None,
+                         "limiter": "fp64 VALU issue + dependency latency (one wave per SIMD); HBM is the stated bound of the path, not the limiter here",
+                         "step_attempts_per_launch": attempts / max(1, launches), "us_per_step_attempt": 1e6 * dev_s / max(1, attempts),
+                         "grid_reduction_us_per_attempt": 1e6 * bar_s / max(1, attempts),
                          "algorithmic_bytes_per_block_iteration": bpi, "block_iterations_per_launch": block_iters / max(1, launches),
                          "avg_launch_us": 1e6 * avg_launch, "launches": launches,
                          "peak_measured_triad": triad, "frac_of_measured_triad": (achieved / triad) if triad else None,
@@ -223,6 +254,22 @@ def main():
                          "note": "stamps and the block Jacobian stay in LDS, so HBM is not the limiter; the kernel is "
                                  "fp64-VALU/latency bound (see DESIGN.md)"},
         }
+        if world == 1 and not args.no_skew and args.tiles == N_TILES:
+            # SURVEY 8(d) config 3 variant: per-tile clock skew U(0, 50 ps), seed 1234 — every tile has its own clock source, the
+            # tiles stop being bit-identical (the worst case for one shared step size).  A second, separate measurement: NOT `value`.
+            rngs = np.random.default_rng(1234)
+            ck = dff_array(args.tiles, skew=rngs.uniform(0.0, 50e-12, args.tiles), observe="q")
+            es = EngineCircuit(ck, ctx)
+            es.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+            t0s = time.perf_counter()
+            rc_s, t_s, v_s, _, st_s = es.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+            el_s = time.perf_counter() - t0s
+            qs = np.array([[np.interp(tt, t_s, v_s[k, :, 0]) for tt in DFF_CHECK_TIMES] for k in range(v_s.shape[0])])
+            line["skewed_clock_variant"] = {"workload": "same array, per-tile clock skew U(0,50 ps) seed 1234 (%d private clock sources)" % args.tiles,
+                                            "rc": rc_s, "ms_per_transient": 1e3 * el_s, "newton_iters_per_sec": st_s["nnonliniter"] / el_s,
+                                            "accepted_steps": st_s["naccept"], "rejected_steps": st_s["nreject"], "step_attempts": st_s["n_step_attempts"],
+                                            "step_controller": "device-resident" if st_s["stepper"] == 2 else "host",
+                                            "every_tile_meets_reference_gate": bool(np.max(np.abs(qs - np.array(DFF_CHECK_Q)[None, :])) <= 10 * TOL)}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         else:

@@ -1164,6 +1164,7 @@ struct ch_circuit {
       if (rc != CH_OK) return rc;
     }
     R.stats.dc_seconds = std::chrono::duration<double>(hclock::now() - tstart).count();
+    dc_block_iters = R.stats.n_block_iters;
     // charges at t0 in the problem's own mode
     {
       NewtonArgs a = base; a.mode = MODE_EVAL; a.maxit = 1; a.hist_slot[0] = order[0]; a.cand_slot = order[0]; a.abstol = o.abstol; a.reltol = o.reltol;
@@ -1172,6 +1173,7 @@ struct ch_circuit {
       R.stats.nf += S;
     }
     htime[0] = t0;
+    dc_device_ms = device_ms; dc_launches = n_launch; dc_timed = n_timed;   // everything so far was initialisation
 
     // break points of every sample's sources
     std::vector<double> bps;
@@ -1335,6 +1337,7 @@ struct ch_circuit {
 
   // shared end of both step controllers: derived observables, final state, statistics
   double persist_ms = 0; long persist_launches = 0; long long persist_attempts = 0; double persist_barrier_s = 0;
+  double dc_device_ms = 0; long dc_launches = 0, dc_timed = 0; long long dc_block_iters = 0;
   int finish_tran(ch_result& R, int newest_slot, double t, int status, hclock::time_point tstart) {
     const int n_obs = R.n_obs;
     const size_t nt = R.times.size();
@@ -1368,6 +1371,13 @@ struct ch_circuit {
     R.stats.n_kernel_launches = n_launch + persist_launches;
     R.stats.n_step_attempts += persist_attempts; R.stats.barrier_seconds = persist_barrier_s;
     R.stats.stepper = persist_launches > 0 ? CH_STEPPER_DEVICE : CH_STEPPER_HOST;
+    R.stats.step_block_iters = R.stats.n_block_iters - dc_block_iters;
+    if (persist_launches > 0) { R.stats.step_kernel_seconds = persist_ms * 1e-3; R.stats.step_kernel_launches = persist_launches; }
+    else {
+      const long nl = n_launch - dc_launches, ntm = n_timed - dc_timed;
+      R.stats.step_kernel_launches = nl;
+      R.stats.step_kernel_seconds = ntm > 0 ? (device_ms - dc_device_ms) * 1e-3 * (double)nl / (double)ntm : 0.0;
+    }
     if (status != CH_OK && err().empty()) set_err(status == CH_ERR_DTMIN ? "step size underflow (DtLessThanMin)" : "transient did not reach t1");
     return status;
   }
@@ -2026,6 +2036,6 @@ int ch_va_eval(ch_ctx* ctx, int32_t id, const double* par, const double* v, doub
 int ch_va_opvars(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* op_out) {
   return guard_rc(ctx, [&] { return ch_va_opvars_impl(ctx, id, par, v, temperature_k, gmin, op_out); });
 }
-const char* ch_version(void) { return "cedarhip 0.1 (gfx950; fused block Newton)"; }
+const char* ch_version(void) { return "cedarhip 0.2 (gfx950; fused block Newton, device-resident step controller)"; }
 
 }  // extern "C"

@@ -163,6 +163,10 @@ typedef struct ch_stats {
   double barrier_seconds;  /* device-resident stepper: time one wave spent inside the grid-wide reductions (0 otherwise) */
   int32_t stepper;         /* which step controller ran: CH_STEPPER_HOST or CH_STEPPER_DEVICE (0 for DC-only calls) */
   int32_t pad_;
+  /* the dominant kernel of the call, for roofline accounting: the time-stepping kernel(s) only, DC initialisation excluded */
+  double step_kernel_seconds;    /* HIP-event time of those launches (device stepper: exact; host stepper: sampled launches, scaled) */
+  int64_t step_kernel_launches;  /* their number (1 per transient on the device stepper, 1 per attempt on the host stepper)         */
+  int64_t step_block_iters;      /* Newton iterations summed over blocks inside them                                               */
 } ch_stats;
 
 /* CedarDCOp options (src/dcop.jl:24-28, 53-94) */

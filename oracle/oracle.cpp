@@ -163,6 +163,10 @@ struct Circuit {
   std::vector<int> mos_dev;  // device index of each MOS
   std::vector<double> va_par; // parameter blocks of the Verilog-A instances
   bool sizes_dirty = true;
+  // "reference-like" proxy of the transient Newton loop: finite-difference Jacobian from
+  // n+1 residual evaluations (AutoFiniteDiff, src/dcop.jl:28,53-94), reused across iterations and steps like IDA's
+  // modified Newton (solve(prob, IDA()), src/sweeps.jl:456; benchmarks/gf180_dff_solver_bench.jl:60-81).  A cost model, not CedarSim.
+  bool proxy_fd_reuse = false;
   std::string err;
 
   int refresh_sizes() {
@@ -186,9 +190,10 @@ struct Eval {
 };
 
 // One residual + Jacobian evaluation: F = i(x,t), Q = q(x), G = di/dx, C = dq/dx.
-static void evaluate(Circuit& c, const double* x, double t, int mode, Eval& e) {
+static void evaluate(Circuit& c, const double* x, double t, int mode, Eval& e, bool resid_only = false) {
   const int n = c.n;
-  e.resize(n);
+  if (resid_only) { e.F.assign(n, 0.0); e.Q.assign(n, 0.0); if (e.G.size() != (size_t)n * n) { e.G.assign((size_t)n * n, 0.0); e.C.assign((size_t)n * n, 0.0); } }
+  else e.resize(n);
   auto V = [&](int node) { return node == 0 ? 0.0 : x[node - 1]; };
   auto addF = [&](int node, double v) { if (node) e.F[node - 1] += v; };
   auto addQ = [&](int node, double v) { if (node) e.Q[node - 1] += v; };
@@ -264,6 +269,12 @@ static void evaluate(Circuit& c, const double* x, double t, int mode, Eval& e) {
         }
       } break;
       case CH_DEV_MOS: {
+        if (resid_only) {   // plain doubles: what one residual call of the reference costs
+          double I[4], Qt[4];
+          b4_eval<double>(c.mos_size[d.mos], V(d.node[0]), V(d.node[1]), V(d.node[2]), V(d.node[3]), c.gmin, I, Qt);
+          for (int k = 0; k < 4; ++k) { addF(d.node[k], m * I[k]); addQ(d.node[k], m * Qt[k]); }
+          break;
+        }
         typedef Dual<4> D4;
         D4 vt[4];
         for (int k = 0; k < 4; ++k) vt[k] = D4::var(V(d.node[k]), k);
@@ -533,6 +544,52 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
     bool conv = false;
     double dn_prev = 0.0, rate_new = -1.0;
     int its_this = 0;
+    if (c.proxy_fd_reuse) {
+      // Modified Newton on a finite-difference Jacobian that is kept while alpha0 stays within 25 % of the value it was
+      // built with and the iteration converges (IDA: cj ratio test, at most 4 iterations, refresh + one retry on failure).
+      static thread_local std::vector<double> Jlu; static thread_local std::vector<int> Jpiv; static thread_local double J_alpha0 = 0.0; static thread_local int J_n = -1;
+      std::vector<double> r0(n), r1(n), xs(n);
+      auto resid = [&](const std::vector<double>& xx, std::vector<double>& r) {
+        evaluate(c, xx.data(), tsrc, 1, e, true); R.stats.nf++;
+        for (int i = 0; i < n; ++i) r[i] = e.F[i] + alpha[0] * e.Q[i] + hq[i];
+      };
+      auto build_jac = [&]() -> bool {
+        resid(xn, r0);
+        Jlu.assign((size_t)n * n, 0.0);
+        xs = xn;
+        for (int j = 0; j < n; ++j) {
+          const double sg = 1.4901161193847656e-08 * std::max(std::fabs(xn[j]), 1.0 / w[j]);
+          xs[j] = xn[j] + sg;
+          resid(xs, r1);
+          const double inv = 1.0 / (xs[j] - xn[j]);
+          for (int i = 0; i < n; ++i) Jlu[(size_t)i * n + j] = (r1[i] - r0[i]) * inv;
+          xs[j] = xn[j];
+        }
+        R.stats.njacs++; R.stats.nfactors++;
+        J_alpha0 = alpha[0]; J_n = n;
+        return lu_factor(Jlu, n, Jpiv);
+      };
+      bool fresh = false;
+      if (J_n != n || !(std::fabs(alpha[0] / J_alpha0 - 1.0) <= 0.25) || step == 0 || hist.size() == 1) { if (!build_jac()) { J_n = -1; } fresh = true; }
+      for (int attempt = 0; attempt < 2 && !conv && J_n == n; ++attempt) {
+        xn = xp; dn_prev = 0.0; its_this = 0;
+        for (int it = 0; it < 4; ++it) {
+          resid(xn, r0);
+          for (int i = 0; i < n; ++i) dx[i] = -r0[i];
+          lu_solve(Jlu, n, Jpiv, dx);
+          R.stats.nsolve++; R.stats.nnonliniter++; ++its_this;
+          bool finite = true;
+          for (int i = 0; i < n; ++i) { xn[i] += dx[i]; if (!std::isfinite(xn[i])) finite = false; }
+          if (!finite) break;
+          const double dn = wrms(dx, w);
+          if (it == 0) { if (dn <= 1e-3) { conv = true; break; } }
+          else { const double rate = dn_prev > 0 ? dn / dn_prev : 0.0; if (rate > 0.9) break; if (dn * std::min(1.0, rate / (1.0 - rate)) <= 0.1 || dn <= 1e-3) { conv = true; break; } }
+          dn_prev = dn;
+        }
+        if (!conv) { if (fresh) break; xn = xp; if (!build_jac()) { J_n = -1; break; } fresh = true; }
+      }
+      if (conv) { evaluate(c, xn.data(), tsrc, 1, e, true); R.stats.nf++; qn = e.Q; }
+    } else
     for (int it = 0; it < nmaxit; ++it) {
       evaluate(c, xn.data(), tsrc, 1, e);
       R.stats.nf++; R.stats.njacs++;
@@ -719,6 +776,8 @@ void* oracle_build(const ch_desc* d) {
 }
 void oracle_free(void* h) { delete (Circuit*)h; }
 int oracle_n_mna(void* h) { return ((Circuit*)h)->n; }
+// 1: transients of this circuit run the finite-difference / Jacobian-reuse cost proxy (see Circuit::proxy_fd_reuse)
+int oracle_set_proxy(void* h, int on) { ((Circuit*)h)->proxy_fd_reuse = on != 0; return CH_OK; }
 int oracle_n_mos(void* h) { return (int)((Circuit*)h)->mos_dev.size(); }
 
 // remake(prob, p=sim) for one sweep point (src/sweeps.jl:476-478)

@@ -25,6 +25,7 @@ def lib():
     L.oracle_free.argtypes = [C.c_void_p]
     L.oracle_n_mna.argtypes = [C.c_void_p]
     L.oracle_n_mos.argtypes = [C.c_void_p]
+    L.oracle_set_proxy.argtypes = [C.c_void_p, C.c_int]
     L.oracle_set_param.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.oracle_dc.argtypes = [C.c_void_p, C.POINTER(ChDcOpts), _pf64, C.POINTER(ChStats)]
     L.oracle_tran.restype = C.c_void_p
@@ -96,6 +97,11 @@ class Oracle:
         out = np.zeros(len(f))
         rc = self.L.oracle_noise(self.h, C.byref(opts), int(out_mna), len(f), _p(f), _p(out))
         return rc, out
+
+    def set_proxy(self, on=True):
+        """Transients run the "reference-like" cost proxy: finite-difference Jacobian (n+1 residuals), reused like IDA's
+        modified Newton.  Off by default: the parity oracle uses exact dual-number Jacobians."""
+        self.L.oracle_set_proxy(self.h, int(bool(on)))
 
     def tran(self, t0, t1, opts=None):
         opts = opts or tran_opts()
