@@ -68,18 +68,27 @@ DFF_CHECK_TIMES = (1.5e-7, 2.5e-7, 4.5e-7, 5.5e-7, 7.0e-7)
 DFF_CHECK_Q = (0.0, 0.0, 5.0, 5.0, 5.0)  # test/gf180_dff.jl:29-33
 
 
-def dff_array(n_tiles=1, skew=None, observe="q", gmin=1e-15):
+def dff_array(n_tiles=1, skew=None, observe="q", gmin=1e-15, supply_r=None):
     """SURVEY §8(d) config 2 (n_tiles=1) and config 3 (n_tiles=1024): tiled DFFs sharing the supplies,
     wells, CLKN and D; each tile has its 12 private nodes, its own CQ and its own VQ ammeter.
 
     skew: optional per-tile clock delay in seconds (array of n_tiles) — gives every tile a private
     clock source (config 3 "optional per-tile clock skew U(0, 50 ps), seed 1234").
+    supply_r: optional series resistance (ohms) between the ideal 5 V / 0 V sources and the VDD / VSS rails: the rails become
+    unknowns shared by every tile, so structural analysis can no longer split the array — ONE coupled Jacobian block of
+    11*n_tiles + 2 unknowns (the literal "assembly + sparse LU" form of config 3; takes the sparse path).
     """
     c = Circuit(gmin=gmin)
     m = gf180_models()
     mi = {"n": c.add_model(*m["nfet_06v0"]), "p": c.add_model(*m["pfet_06v0"])}
-    c.V("vvdd", "vdd", 0, dc=5.0)
-    c.V("vvss", "vss", 0, dc=0.0)
+    if supply_r is None:
+        c.V("vvdd", "vdd", 0, dc=5.0)
+        c.V("vvss", "vss", 0, dc=0.0)
+    else:
+        c.V("vvdd", "vdd_src", 0, dc=5.0)
+        c.R("rvdd", "vdd_src", "vdd", float(supply_r))
+        c.V("vvss", "vss_src", 0, dc=0.0)
+        c.R("rvss", "vss_src", "vss", float(supply_r))
     c.V("vnw", "vnw", "vdd", dc=0.0)
     c.V("vpw", "vpw", "vss", dc=0.0)
     if skew is None:

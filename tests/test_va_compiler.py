@@ -412,3 +412,28 @@ def test_switch_branch_state_semantics():
         c.R("rl", "out", 0, 1e3)
         rc, x, _ = Oracle(c).dc(dc_opts(abstol=1e-15))
         assert rc == 0 and x[c._n("out") - 1] == pytest.approx(want, rel=1e-9)
+
+
+def test_generated_code_matches_hand_derived_closed_forms(oracle_lib):
+    """The compiler (front end + code generator) against stamps derived by hand from the model equations
+    (tests/golden/make_va_closed_form.py shares nothing with cedarsim.jl_amd/va): g++ build of the generated code here,
+    the HIP build in tests/test_gpu_parity_wide.py."""
+    import ctypes as C
+    import json
+    import os
+    import numpy as np
+    from cedarsim_jl_amd.va.registry import find_module
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "va_closed_form.json")))
+    pd = C.POINTER(C.c_double)
+    for case in g["cases"]:
+        mid, _ = find_module(case["module"])
+        P = np.array(case["par_block"], float)
+        v = np.zeros(8)
+        v[:len(case["v"])] = case["v"]
+        ref = np.zeros(144)
+        assert oracle_lib.oracle_va_eval(mid, P.ctypes.data_as(pd), v.ctypes.data_as(pd), case["temperature_k"], 0.0, ref.ctypes.data_as(pd)) == 0
+        I, G = ref[:8], ref[16:80].reshape(8, 8)
+        for k, w in case["I"]:
+            assert abs(I[k] - w) <= 1e-12 * max(1.0, abs(w)) + 1e-25, (case["module"], "I", k)
+        for r, c, w in case["G"]:
+            assert abs(G[r, c] - w) <= 1e-11 * max(1.0, abs(w)) + 1e-25, (case["module"], "G", r, c)
