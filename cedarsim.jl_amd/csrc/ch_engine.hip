@@ -1057,7 +1057,7 @@ struct ch_circuit {
     HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(bps, st));
     { std::vector<double> sv(o.saveat, o.saveat + std::max(0, o.n_saveat)); if (sv.empty()) sv.push_back(0.0); HIPCHK(d_psave.upload(sv, st)); }
     HIPCHK(d_ptimes.alloc((size_t)max_rows)); HIPCHK(d_prows.alloc((size_t)max_rows * row_d));
-    HIPCHK(d_wgrec.alloc((size_t)n_wg * P_NREC)); HIPCHK(d_grprec.alloc(8 * P_NREC)); HIPCHK(d_pcnt.alloc(10 * 32)); HIPCHK(d_pctl.alloc(1));
+    HIPCHK(d_wgrec.alloc((size_t)2 * n_wg * 16)); HIPCHK(d_grprec.alloc(2 * 8 * 16)); /* 16 granules per record, double-buffered by generation parity */ HIPCHK(d_pcnt.alloc(10 * 32)); HIPCHK(d_pctl.alloc(1));
     PersistArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.a = base;
     pa.a.mode = MODE_TRAN; pa.a.maxit = nmaxit; pa.a.abstol = o.abstol; pa.a.reltol = o.reltol; pa.a.newton_tol = 0.1; pa.a.active = nullptr; pa.a.gshunt = 0.0;
@@ -1068,6 +1068,8 @@ struct ch_circuit {
     pa.out_times = d_ptimes.p; pa.out_rows = d_prows.p; pa.max_rows = max_rows; pa.n_obs = n_obs;
     pa.ctl = d_pctl.p; pa.wg_rec = d_wgrec.p; pa.grp_rec = d_grprec.p; pa.counters = d_pcnt.p;
     pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz
+    // a batch of single-block samples on a common output grid: every sample its own step sequence (no lock-step, no grid reduction)
+    pa.indep = (A.n_comp == 1 && S > 1 && o.n_saveat > 0 && std::getenv("CEDARHIP_LOCKSTEP") == nullptr) ? 1 : 0;
     pa.pair_dbg = std::getenv("CEDARHIP_PAIR_DBG") ? std::atoi(std::getenv("CEDARHIP_PAIR_DBG")) : 0;
     // initial controller state (same first step as the host stepper)
     TranCtl cs; std::memset(&cs, 0, sizeof(cs));
@@ -1089,6 +1091,7 @@ struct ch_circuit {
     for (;;) {
       HIPCHK(hipMemcpyAsync(d_pctl.p, &cs, sizeof(cs), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemsetAsync(d_pcnt.p, 0, 10 * 32 * sizeof(unsigned), st));
+      HIPCHK(hipMemsetAsync(d_wgrec.p, 0, (size_t)2 * n_wg * 16 * sizeof(double), st)); HIPCHK(hipMemsetAsync(d_grprec.p, 0, 2 * 8 * 16 * sizeof(double), st));   // generation tags start at 0
       pa.resume = resume;
       void* kargs[] = {(void*)&pa};
       HIPCHK(hipEventRecord(ev0, st));

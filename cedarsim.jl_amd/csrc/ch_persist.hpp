@@ -57,6 +57,8 @@ struct PersistArgs {
   double* wg_rec; double* grp_rec; unsigned* counters;   // grid reduction: [n_wg][8], [8][8], 10 counters on 128-byte lines
   long long spin_ticks;       // bound of every spin, in wall_clock64 ticks (100 MHz)
   int pair_dbg;               // diagnostic: 1 = the first wave of a pair evaluates both halves itself (A/B of the function split)
+  int indep;                  // 1: a batch of single-block samples on a common saveat grid — every sample (pair of samples when PAIR)
+                              //    runs its own controller: no grid-wide reduction at all, each takes exactly the steps it needs
 };
 
 // ---- constants blob layout -------------------------------------------------------------------
@@ -184,52 +186,104 @@ __device__ __forceinline__ double p_tree(double v, bool is_max) {
 
 // Grid-wide reduction of one 8-double record per wave; every wave of the grid returns with the combined record in summ[].
 // Record: [0..2] error sums (or per-sample ratios when red_max), [3] ndiff, [4] max iterations, [5] sum of iterations, [6] failures.
-// Fields 0..2 are combined with + (S == 1) or max (n_comp == 1); 3, 5, 6 with +; 4 with max.  Returns false on abort.
+// Fields 0..2 are combined with + (S == 1) or max (n_comp == 1); 3, 5, 6, 7 with +; 4 with max.  Returns false on abort.
+//
+// Transport: data-tagged 8-byte granules {32-bit half of a double | 32-bit generation}, written with ONE relaxed agent-scope
+// store each and polled in place — no payload-then-flag pair, no wait for a store to land, no counter (the price list of
+// MI355X_MICROARCH.md: a granule hand-off is one fabric latency, a store + drained flag two to three).  A record is 16 granules
+// (128 bytes).  Two levels: every workgroup publishes its record; the leaders (workgroups 0..7) sweep the records of workgroups
+// g, g+8, g+16, ... and publish a group record; every workgroup sweeps the (at most) eight group records.  All sums are taken
+// in a fixed order.  Records are double-buffered by the parity of the generation: a group may publish generation g+1 while
+// a slow workgroup is still sweeping generation g, but never g+2.
+typedef unsigned long long p_u64;
+__device__ __forceinline__ p_u64 ld_gran(const p_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_gran(p_u64* p, p_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// lanes 2f and 2f+1 of every 16-lane group hold the low and the high half of field f: both get the double back
+__device__ __forceinline__ double p_join(p_u64 gran, int lane) {
+  const unsigned mine = (unsigned)gran, other = (unsigned)__shfl_xor((int)mine, 1);
+  const unsigned lo = (lane & 1) ? other : mine, hi = (lane & 1) ? mine : other;
+  return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ p_u64 p_split(double v, int lane, unsigned gen) {
+  const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+  return ((p_u64)gen << 32) | half;
+}
 __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const double* rec /* 8 wave-uniform values */, double* part, double* summ,
                                      int* s_abort, int wave, int lane, int wg) {
-  const int f = lane & 7, m = lane >> 3;
+  const int g16 = lane & 15, f = g16 >> 1, m4 = lane >> 4;   // granule of the record, its field, member slot of a sweep
   const bool fmaxop = (f == 4) || (p.red_max && f < 3);
   if (lane < P_NREC) {
     double v = rec[0];
 #pragma unroll
-    for (int q = 1; q < P_NREC; ++q) v = (f == q) ? rec[q] : v;
-    part[wave * P_NREC + f] = v;
+    for (int q = 1; q < P_NREC; ++q) v = (lane == q) ? rec[q] : v;
+    part[wave * P_NREC + lane] = v;
   }
   __syncthreads();
   const int n_grp = p.n_wg < 8 ? p.n_wg : 8;
   const int grp = wg & 7;
   unsigned* abort_flag = p.counters + 9 * 32;
+  p_u64* wrec = (p_u64*)p.wg_rec + (size_t)(gen & 1) * p.n_wg * 16;
+  p_u64* grec = (p_u64*)p.grp_rec + (size_t)(gen & 1) * 8 * 16;
   if (wave == 0) {
     bool ok = true;
-    double v = 0.0;
-    if (lane < P_NREC) {
-      v = part[f];
+    double v = part[f];
 #pragma unroll
-      for (int w = 1; w < PW; ++w) { const double u = part[w * P_NREC + f]; v = fmaxop ? fmax(v, u) : v + u; }
-    }
+    for (int w = 1; w < PW; ++w) { const double u = part[w * P_NREC + f]; v = fmaxop ? fmax(v, u) : v + u; }
     if (p.n_wg > 1) {
-      if (lane < P_NREC) st_agent(p.wg_rec + (long)wg * P_NREC + f, v);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(p.counters + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (wg < n_grp) {   // group leader: fold the records of the workgroups wg, wg + 8, wg + 16, ...
+      if (lane < 16) st_gran(wrec + (size_t)wg * 16 + g16, p_split(v, lane, gen));
+      const long long t0 = wall_clock64();
+      if (wg < n_grp) {   // group leader: the records of workgroups wg, wg + 8, wg + 16, ... (at most 32), four per sweep load
         const int members = (p.n_wg - grp + 7) >> 3;
-        ok = p_wait(p.counters + grp * 32, gen * (unsigned)members, abort_flag, p.spin_ticks);
+        p_u64 x[8];
+        for (;;) {
+          bool all = true;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int mm = q * 4 + m4;
+            x[q] = mm < members ? ld_gran(wrec + (size_t)(grp + 8 * mm) * 16 + g16) : ((p_u64)gen << 32);
+            all = all && (unsigned)(x[q] >> 32) == gen;
+          }
+          if (__all(all)) break;
+          if (ld_agent_u(abort_flag) != 0u) { ok = false; break; }
+          if (wall_clock64() - t0 > p.spin_ticks) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
         double acc = 0.0;
-        for (int base = 0; base < members; base += 8) {
-          const int mm = base + m;
-          double u = (ok && mm < members) ? ld_agent(p.wg_rec + (long)(grp + 8 * mm) * P_NREC + f) : 0.0;
-          u = p_tree(u, fmaxop);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          double u = (q * 4 + m4 < members) ? p_join(x[q], lane) : 0.0;
+          u = fmaxop ? fmax(u, __shfl_xor(u, 16)) : u + __shfl_xor(u, 16);
+          u = fmaxop ? fmax(u, __shfl_xor(u, 32)) : u + __shfl_xor(u, 32);
           acc = fmaxop ? fmax(acc, u) : acc + u;
         }
-        if (lane < P_NREC) st_agent(p.grp_rec + grp * P_NREC + f, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.counters + 8 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 16) st_gran(grec + (size_t)grp * 16 + g16, p_split(acc, lane, gen));
       }
-      ok = p_wait(p.counters + 8 * 32, gen * (unsigned)n_grp, abort_flag, p.spin_ticks) && ok;
-      double u = (ok && m < n_grp) ? ld_agent(p.grp_rec + m * P_NREC + f) : 0.0;
-      v = p_tree(u, fmaxop);
+      // every workgroup: the group records (8 x 16 granules = two per lane)
+      p_u64 y[2];
+      for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int gg = q * 4 + m4;
+          y[q] = (ok && gg < n_grp) ? ld_gran(grec + (size_t)gg * 16 + g16) : ((p_u64)gen << 32);
+          all = all && (unsigned)(y[q] >> 32) == gen;
+        }
+        if (__all(all) || !ok) break;
+        if (ld_agent_u(abort_flag) != 0u) { ok = false; break; }
+        if (wall_clock64() - t0 > p.spin_ticks) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        double u = (q * 4 + m4 < n_grp) ? p_join(y[q], lane) : 0.0;
+        u = fmaxop ? fmax(u, __shfl_xor(u, 16)) : u + __shfl_xor(u, 16);
+        u = fmaxop ? fmax(u, __shfl_xor(u, 32)) : u + __shfl_xor(u, 32);
+        acc = fmaxop ? fmax(acc, u) : acc + u;
+      }
+      v = acc;
     }
-    if (lane < P_NREC) summ[f] = v;
+    if (lane < 16 && !(lane & 1)) summ[f] = v;
     if (lane == 0) *s_abort = ok ? 0 : 1;
   }
   __syncthreads();
@@ -630,12 +684,34 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     ++gen;
     P_STAMP(9);   // candidate, local-error sums
     const long long cb0 = wall_clock64();
-    const bool okr = p_grid_reduce(p, gen, rec, part, summ, &s_abort, wave, lane, wg);
+    double sA, sB, sC, sN, sItMax, sItSum, sFail;
+    if (p.indep) {
+      // per-sample step acceptance: the record is combined over the wave pair only (the two samples that share a device
+      // evaluation stay in lock-step), or not at all
+      double r8[P_NREC];
+#pragma unroll
+      for (int q = 0; q < P_NREC; ++q) r8[q] = rec[q];
+      if (PAIR) {
+        if (lane < P_NREC) { double v = rec[0];
+#pragma unroll
+          for (int q = 1; q < P_NREC; ++q) v = (lane == q) ? rec[q] : v;
+          part[wave * P_NREC + lane] = v; }
+        pair_sync();
+        const double* other = part + (wave ^ 1) * P_NREC;
+#pragma unroll
+        for (int q = 0; q < P_NREC; ++q) { const double o = other[q]; r8[q] = (q < 3 || q == 4) ? fmax(r8[q], o) : r8[q] + o; }
+        if (pair_broken) r8[7] = 1.0;
+      }
+      sA = r8[0]; sB = r8[1]; sC = r8[2]; sN = r8[3]; sItMax = r8[4]; sItSum = (double)iters; sFail = r8[6];
+      if (r8[7] != 0.0) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
+    } else {
+      const bool okr = p_grid_reduce(p, gen, rec, part, summ, &s_abort, wave, lane, wg);
+      if (!okr || summ[7] != 0.0) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
+      sA = summ[0]; sB = summ[1]; sC = summ[2]; sN = summ[3]; sItMax = summ[4]; sItSum = summ[5]; sFail = summ[6];
+      __syncthreads();   // summ is rewritten by the next reduction
+    }
     cyc_bar += wall_clock64() - cb0;
     P_STAMP(10);  // grid reduction
-    if (!okr || summ[7] != 0.0) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
-    const double sA = summ[0], sB = summ[1], sC = summ[2], sN = summ[3], sItMax = summ[4], sItSum = summ[5], sFail = summ[6];
-    __syncthreads();   // summ is rewritten by the next reduction
     // error norms of orders k, k-1, k+1 in lanes 0, 1, 2 (one division and one square root for the three)
     double errk, errkm1, errkp1;
     double ev3;
@@ -734,6 +810,18 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       a.Qh[(long)j * a.slot_stride + sofs + lane] = Qh[sl * nc + lane];
     }
   }
+  if (p.indep) {
+    // every sample reports for itself: sums of iterations, the longest chain of attempts, the worst status
+    if (live && lane == 0) {
+      TranCtl* cs = p.ctl;
+      typedef unsigned long long u64;
+      atomicAdd((u64*)&cs->sum_iters, (u64)stl[ST_ITERS]); atomicAdd((u64*)&cs->sum_block_iters, (u64)stl[ST_BITERS]);
+      atomicMax((u64*)&cs->naccept, (u64)stl[ST_ACC]); atomicMax((u64*)&cs->nreject, (u64)stl[ST_REJ]); atomicMax((u64*)&cs->nconvfail, (u64)stl[ST_FAIL]);
+      atomicMax((u64*)&cs->n_attempts, (u64)stl[ST_ATT]); atomicMax((u64*)&cs->nsaved, (u64)nsaved);
+      atomicMin(&cs->status, status); atomicMax(&cs->exit_reason, exit_reason);
+      if (blk == 0) { cs->t = t; cs->h = h; cs->isave = isave; cs->t_cycles_total = wall_clock64() - cyc0; cs->t_cycles_barrier = cyc_bar; }
+    }
+  } else
   if (wg == 0 && wave == 0 && lane == 0) {
     TranCtl* cs = p.ctl;
     cs->t = t; cs->h = h; cs->k = k; cs->nhist = nhist; cs->steps_at_order = steps_at_order; cs->reset_rate = reset_rate ? 1 : 0;

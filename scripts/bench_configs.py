@@ -64,7 +64,8 @@ if only in ("all", "config4_share"):
         rc, t, v, xf, st = e.tran(0.0, 7e-7, opts)
         el = time.perf_counter() - t0
         ok = np.abs(v[0] - np.array(DFF_CHECK_Q)[:, None]) < 1e-3
-        res[stepper] = {"rc": rc, "wall_seconds": el, "step_attempts": st["n_step_attempts"], "us_per_attempt": 1e6 * el / max(1, st["n_step_attempts"]),
+        res[stepper] = {"rc": rc, "wall_seconds": el, "dc_seconds": st["dc_seconds"], "transient_seconds": el - st["dc_seconds"], "step_attempts": st["n_step_attempts"],
+                        "us_per_attempt": 1e6 * (el - st["dc_seconds"]) / max(1, st["n_step_attempts"]),
                         "block_iterations_per_second": st["n_block_iters"] / el, "samples_passing_reference_gate": int(ok.all(axis=0).sum())}
     out["config4_share_mc1024"] = {"samples": S, "note": "the per-GPU share of the 8192-sample Monte-Carlo on an 8-GPU node", **res}
 if only in ("all", "coupled"):

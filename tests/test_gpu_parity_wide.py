@@ -89,21 +89,22 @@ def test_spsin_with_delay_damping_phase_and_cycle_limit(E):
     vo + va*exp(-(t-td)*theta)*sind(360 f (t-td) + phase) for td < t < ncycles/f and vo + va*sind(phase) outside."""
     vo, va, f, td, th, ph, ncy = 0.3, 1.5, 2e5, 2e-6, 1.5e5, 40.0, 3.0
     c = Circuit()
-    c.V("v", "a", 0, dc=0.0, tran=SIN(vo, va, f, td, th, ph, ncy))
+    c.V("v", "a", 0, dc=vo + va * math.sin(math.radians(ph)), tran=SIN(vo, va, f, td, th, ph, ncy))   # the DC point is the value before the delay
     c.R("r1", "a", "b", 1e3)
     c.R("r2", "b", 0, 1e3)
     c.observe_node("b")
     e = E(c)
-    sv = np.linspace(0.0, 2.2e-5, 881)
     sind = lambda d: np.sin(np.fmod(d, 360.0) * math.pi / 180.0)  # noqa: E731
-    inside = (sv > td) & (sv < ncy / f)
-    want = np.where(inside, vo + va * np.exp(-(sv - td) * th) * sind(360.0 * f * (sv - td) + ph), vo + va * sind(ph)) / 2
     for stepper in ("host", "device"):
-        rc, t, v, _, st = e.tran(0.0, 2.2e-5, tran_opts(abstol=1e-9, reltol=1e-7, saveat=sv, stepper=stepper))
-        assert rc == 0 and np.array_equal(t, sv)
-        # the source jumps at td and at ncycles/f: compare away from the two jumps (dense output interpolates across them)
-        m = (np.abs(sv - td) > 1e-7) & (np.abs(sv - ncy / f) > 1e-7)
-        assert np.max(np.abs(v[0, m, 0] - want[m])) < 2e-6, stepper
+        # a purely resistive circuit has no local error: the integrator strides to dtmax, so the check is made AT the accepted
+        # points (every one of them is an exact algebraic solve), not on an interpolated grid
+        rc, t, v, _, st = e.tran(0.0, 2.2e-5, tran_opts(abstol=1e-9, reltol=1e-7, dtmax=2e-7, stepper=stepper))
+        assert rc == 0 and len(t) > 100
+        inside = (t > td) & (t < ncy / f)
+        want = np.where(inside, vo + va * np.exp(-(t - td) * th) * sind(360.0 * f * (t - td) + ph), vo + va * sind(ph)) / 2
+        m = (t != td) & (t != ncy / f)     # landing on a break point uses the source's left limit there
+        assert np.max(np.abs(v[0, m, 0] - want[m])) < 1e-9, stepper
+        assert np.any(t == td) and np.any(t == ncy / f)   # both break points are hit exactly
 
 
 def test_pwl_corner_belongs_to_the_next_segment_on_the_device(E):
@@ -126,7 +127,7 @@ def test_pwl_corner_belongs_to_the_next_segment_on_the_device(E):
         if t < 4e-6:
             return 1e-3 * (4e-6 - t) / 1e-6
         return -5e-4
-    q = np.array([np.trapz([wave(u) for u in np.linspace(0.0, t, 4001)], np.linspace(0.0, t, 4001)) if t > 0 else 0.0 for t in sv])
+    q = np.array([np.trapezoid([wave(u) for u in np.linspace(0.0, t, 4001)], np.linspace(0.0, t, 4001)) if t > 0 else 0.0 for t in sv])
     e = E(c)
     for stepper in ("host", "device"):
         rc, t, v, _, _ = e.tran(0.0, 6e-6, tran_opts(abstol=1e-9, reltol=1e-8, saveat=sv, stepper=stepper))
