@@ -246,7 +246,8 @@ struct ch_circuit {
   // ---- sparse path (blocks too large for LDS) ----
   int path = 1;                 // 1 = fused block kernel, 2 = sparse level-scheduled LU
   SparsePlan plan[2];           // [0] DC (alpha0 = 0), [1] transient
-  struct PlanDev { DevBuf<int> prow, pcol, a2lu, diag_pos, lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows, lrow_ptr, l_pos, l_k, l_upd_ptr, upd_dst, upd_src, urow_ptr, u_pos, u_col; DevBuf<double> LUv; } plan_dev[2];
+  struct PlanDev { DevBuf<int> prow, pcol, a2lu, diag_pos, lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows, lrow_ptr, l_pos, l_k, l_upd_ptr, upd_dst, upd_src, urow_ptr, u_pos, u_col;
+                   DevBuf<int> lu2a, la_pos, la_diag, lb_dst, lb_sptr, lb_l, lb_u, lb_d, fl_rows, bl_rows; DevBuf<double> LUv, Lv; } plan_dev[2];
   DevBuf<int> sp_dflag;
   DevBuf<int> sp_rowptr, sp_colidx, sp_mat_gptr, sp_mat_gsrc, sp_vec_gptr, sp_vec_gsrc;
   DevBuf<double> sp_stage, sp_Aval, sp_Cval, sp_F, sp_Q, sp_rhs, sp_y, sp_dx, sp_xcur, sp_xpred, sp_hq, sp_w, sp_qn;
@@ -649,6 +650,9 @@ struct ch_circuit {
     d.prow = pd.prow.p; d.pcol = pd.pcol.p; d.a2lu = pd.a2lu.p; d.diag_pos = pd.diag_pos.p; d.lvl_ptr = pd.lvl_ptr.p; d.lvl_rows = pd.lvl_rows.p;
     d.ulvl_ptr = pd.ulvl_ptr.p; d.ulvl_rows = pd.ulvl_rows.p; d.lrow_ptr = pd.lrow_ptr.p; d.l_pos = pd.l_pos.p; d.l_k = pd.l_k.p; d.l_upd_ptr = pd.l_upd_ptr.p;
     d.upd_dst = pd.upd_dst.p; d.upd_src = pd.upd_src.p; d.urow_ptr = pd.urow_ptr.p; d.u_pos = pd.u_pos.p; d.u_col = pd.u_col.p;
+    d.lu2a = pd.lu2a.p; d.la_pos = pd.la_pos.p; d.la_diag = pd.la_diag.p; d.lb_dst = pd.lb_dst.p; d.lb_sptr = pd.lb_sptr.p; d.lb_l = pd.lb_l.p; d.lb_u = pd.lb_u.p; d.lb_d = pd.lb_d.p;
+    d.fl_rows = pd.fl_rows.p; d.bl_rows = pd.bl_rows.p;
+    d.Lv = pd.Lv.p ? pd.Lv.p + (size_t)sm * (size_t)std::max(0, P.nnz_lu) : nullptr;
     d.s = sm; d.xofs = (long)sm * (long)n;
     d.st_stage = (long)(nd * A.stride()); d.st_nnz = (long)nnz; d.st_lu = (long)std::max(0, P.nnz_lu); d.st_n = (long)n;
     d.stride = A.stride(); d.q_ofs = A.wide ? 8 : 4; d.c_ofs = A.wide ? 64 : 16; d.wide = A.wide ? 1 : 0;
@@ -677,7 +681,42 @@ struct ch_circuit {
     HIPCHK(pd.lrow_ptr.upload(P.lrow_ptr, st)); HIPCHK(pd.l_pos.upload(P.l_pos, st)); HIPCHK(pd.l_k.upload(P.l_k, st)); HIPCHK(pd.l_upd_ptr.upload(P.l_upd_ptr, st));
     HIPCHK(pd.upd_dst.upload(P.upd_dst, st)); HIPCHK(pd.upd_src.upload(P.upd_src, st)); HIPCHK(pd.urow_ptr.upload(P.urow_ptr, st)); HIPCHK(pd.u_pos.upload(P.u_pos, st)); HIPCHK(pd.u_col.upload(P.u_col, st));
     HIPCHK(pd.LUv.alloc((size_t)S * (size_t)P.nnz_lu));
+    if (P.wide_levels && std::getenv("CEDARHIP_SPARSE_ONE_WG") == nullptr) {
+      std::vector<int> lu2a((size_t)P.nnz_lu, -1);
+      for (size_t i = 0; i < P.a2lu.size(); ++i) lu2a[P.a2lu[i]] = (int)i;
+      HIPCHK(pd.lu2a.upload(lu2a, st)); HIPCHK(pd.la_pos.upload(P.la_pos, st)); HIPCHK(pd.la_diag.upload(P.la_diag, st));
+      HIPCHK(pd.lb_dst.upload(P.lb_dst, st)); HIPCHK(pd.lb_sptr.upload(P.lb_sptr, st)); HIPCHK(pd.lb_l.upload(P.lb_l, st)); HIPCHK(pd.lb_u.upload(P.lb_u, st)); HIPCHK(pd.lb_d.upload(P.lb_d, st));
+      HIPCHK(pd.fl_rows.upload(P.fl_rows, st)); HIPCHK(pd.bl_rows.upload(P.bl_rows, st));
+      HIPCHK(pd.Lv.alloc((size_t)S * (size_t)P.nnz_lu));
+    } else P.wide_levels = false;
     return CH_OK;
+  }
+  // refactorisation + both triangular solves for the samples of `wl`: one workgroup per sample (chains, small systems), or
+  // one launch per elimination level across the whole chip (few wide levels)
+  void launch_lu_solve(int which, const int* wl, size_t n_work) {
+    hipStream_t st = ctx->stream;
+    const SparsePlan& P = plan[which];
+    const SparseDev d = sparse_dev(which);
+    if (!P.wide_levels) { hipLaunchKernelGGL(sp_lu_solve_kernel, dim3(1, (unsigned)n_work), dim3(1024), 0, st, d, wl); return; }
+    const unsigned ny = (unsigned)n_work;
+    hipLaunchKernelGGL(sp2_scatter_kernel, dim3((unsigned)((P.nnz_lu + 255) / 256), ny), dim3(256), 0, st, d, wl);
+    const int nl = (int)P.lvl_ptr.size() - 1, nul = (int)P.ulvl_ptr.size() - 1;
+    for (int l = 0; l < P.n_rlvl; ++l) {
+      const int nA = P.la_ptr[l + 1] - P.la_ptr[l], nB = P.lb_ptr[l + 1] - P.lb_ptr[l], nBh = P.lb_nheavy[l], nBl = nB - nBh;
+      if (nA + nB == 0) continue;
+      const int tb = (nA + nBl + 255) / 256, hb = (nBh + 3) / 4;
+      hipLaunchKernelGGL(sp2_factor_level_kernel, dim3((unsigned)std::max(1, tb + hb), ny), dim3(256), 0, st, d, wl, P.la_ptr[l], nA, P.lb_ptr[l], nBl, nBh, tb);
+    }
+    for (int l = 0; l < nl; ++l) {
+      const int nr = P.fl_ptr[l + 1] - P.fl_ptr[l], nh = P.fl_nheavy[l], nlg = nr - nh;
+      const int tb = (nlg + 255) / 256, hb = (nh + 3) / 4;
+      hipLaunchKernelGGL(sp2_fwd_level_kernel, dim3((unsigned)std::max(1, tb + hb), ny), dim3(256), 0, st, d, wl, P.fl_ptr[l], nlg, nh, tb);
+    }
+    for (int l = 0; l < nul; ++l) {
+      const int nr = P.bl_ptr[l + 1] - P.bl_ptr[l];
+      hipLaunchKernelGGL(sp2_bwd_level_kernel, dim3((unsigned)((nr + 255) / 256), ny), dim3(256), 0, st, d, wl, P.bl_ptr[l], nr);
+    }
+    n_launch += 1 + P.n_rlvl + nl + nul;
   }
   // Small-signal analyses see the circuit as dense blocks: the Jacobian blocks of the fused path, or — on the sparse path —
   // the whole system as one block per sample (up to 96 unknowns the complex LU runs in LDS, above that in a global workspace)
@@ -784,7 +823,7 @@ struct ch_circuit {
       const int* wl = sp_act[1].p;
       for (int attempt = 0; attempt < 2 && !work.empty(); ++attempt) {
         const SparseDev d = sparse_dev(which);
-        hipLaunchKernelGGL(sp_lu_solve_kernel, grid(1, work.size()), b1k, 0, st, d, wl);
+        launch_lu_solve(which, wl, work.size());
         const double* sc = nullptr;
         if (damp) {
           hipLaunchKernelGGL(sp_norms_kernel, grid(1, work.size()), b1k, 0, st, a, d, wl, 1);

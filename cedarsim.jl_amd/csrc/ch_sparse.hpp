@@ -36,6 +36,9 @@ struct SparseDev {
   const int* lvl_ptr; const int* lvl_rows; const int* ulvl_ptr; const int* ulvl_rows;
   const int* lrow_ptr; const int* l_pos; const int* l_k; const int* l_upd_ptr; const int* upd_dst; const int* upd_src;
   const int* urow_ptr; const int* u_pos; const int* u_col;
+  // level-synchronous form (multi-workgroup kernels)
+  const int* lu2a; const int* la_pos; const int* la_diag; const int* lb_dst; const int* lb_sptr; const int* lb_l; const int* lb_u; const int* lb_d;
+  const int* fl_rows; const int* bl_rows; double* Lv;
   int n, nnz, nnz_lu, n_lvl, n_ulvl, n_dev;
   int s; long xofs;                // sample handled by this workgroup; its offset s*n inside a slot of the state ring
   long st_stage, st_nnz, st_lu, st_n;  // per-sample strides of the work arrays (the struct is built for sample 0)
@@ -53,7 +56,7 @@ struct SparseDev {
 __device__ __forceinline__ SparseDev sp_pick(SparseDev d, const int* act) {
   const int sm = act[blockIdx.y];
   d.s = sm; d.xofs = (long)sm * d.st_n;
-  d.stage += sm * d.st_stage; d.Aval += sm * d.st_nnz; d.Cval += sm * d.st_nnz; if (d.LUv) d.LUv += sm * d.st_lu;
+  d.stage += sm * d.st_stage; d.Aval += sm * d.st_nnz; d.Cval += sm * d.st_nnz; if (d.LUv) d.LUv += sm * d.st_lu; if (d.Lv) d.Lv += sm * d.st_lu;
   d.F += sm * d.st_n; d.Q += sm * d.st_n; d.rhs += sm * d.st_n; d.y += sm * d.st_n; d.dx += sm * d.st_n;
   d.xcur += sm * d.st_n; d.xpred += sm * d.st_n; d.hq += sm * d.st_n; d.w += sm * d.st_n; d.qn += sm * d.st_n;
   d.red += (long)sm * 8; d.flag += (long)sm * 2; d.dflag += sm;
@@ -138,23 +141,61 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
   if (d.wide) widen_stamp(st, st_final);
 }
 
-// CSR gather assembly: one thread per nnz and per row
-__global__ void sp_assemble_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
+// CSR gather assembly: one thread per nnz and per row; an entry or row with more than 64 sources (a supply rail shared by
+// every tile collects one stamp per attached device) is summed by the whole wavefront, lanes striding over the sources and a
+// fixed-order tree at the end — deterministic either way.
+__device__ __forceinline__ double sp_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__global__ __launch_bounds__(256) void sp_assemble_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
   const SparseDev d = sp_pick(d0, act);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wbase = i - lane;
   const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
-  if (i < d.nnz) {
-    double g = 0.0, c = 0.0;
-    for (int p = d.mat_gptr[i]; p < d.mat_gptr[i + 1]; ++p) { const int o = d.mat_gsrc[p]; g += d.stage[o]; c += d.stage[o + d.c_ofs]; }
-    d.Aval[i] = g + alpha0 * c; d.Cval[i] = c;
+  {
+    const int p0 = i < d.nnz ? d.mat_gptr[i] : 0, p1 = i < d.nnz ? d.mat_gptr[i + 1] : 0;
+    const bool heavy = p1 - p0 > 64;
+    if (i < d.nnz && !heavy) {
+      double g = 0.0, c = 0.0;
+      for (int p = p0; p < p1; ++p) { const int o = d.mat_gsrc[p]; g += d.stage[o]; c += d.stage[o + d.c_ofs]; }
+      d.Aval[i] = g + alpha0 * c; d.Cval[i] = c;
+    }
+    unsigned long long hm = __ballot(heavy);
+    while (hm) {
+      const int l = __ffsll((long long)hm) - 1; hm &= hm - 1;
+      const int e = wbase + l;
+      double g = 0.0, c = 0.0;
+      for (int p = d.mat_gptr[e] + lane; p < d.mat_gptr[e + 1]; p += 64) { const int o = d.mat_gsrc[p]; g += d.stage[o]; c += d.stage[o + d.c_ofs]; }
+      g = sp_wave_sum(g); c = sp_wave_sum(c);
+      if (lane == 0) { d.Aval[e] = g + alpha0 * c; d.Cval[e] = c; }
+    }
   }
-  if (i < d.n) {
-    double f = 0.0, q = 0.0;
-    for (int p = d.vec_gptr[i]; p < d.vec_gptr[i + 1]; ++p) { const int o = d.vec_gsrc[p]; f += d.stage[o]; q += d.stage[o + d.q_ofs]; }
-    if (a.gshunt != 0.0 && !(a.dmask[i] & 2)) f += a.gshunt * d.xcur[i];
-    d.Q[i] = q;
-    const double F = f + alpha0 * q + d.hq[i];
-    d.F[i] = F; d.rhs[i] = -F;
+  {
+    const int p0 = i < d.n ? d.vec_gptr[i] : 0, p1 = i < d.n ? d.vec_gptr[i + 1] : 0;
+    const bool heavy = p1 - p0 > 64;
+    if (i < d.n && !heavy) {
+      double f = 0.0, q = 0.0;
+      for (int p = p0; p < p1; ++p) { const int o = d.vec_gsrc[p]; f += d.stage[o]; q += d.stage[o + d.q_ofs]; }
+      if (a.gshunt != 0.0 && !(a.dmask[i] & 2)) f += a.gshunt * d.xcur[i];
+      d.Q[i] = q;
+      const double F = f + alpha0 * q + d.hq[i];
+      d.F[i] = F; d.rhs[i] = -F;
+    }
+    unsigned long long hm = __ballot(heavy);
+    while (hm) {
+      const int l = __ffsll((long long)hm) - 1; hm &= hm - 1;
+      const int e = wbase + l;
+      double f = 0.0, q = 0.0;
+      for (int p = d.vec_gptr[e] + lane; p < d.vec_gptr[e + 1]; p += 64) { const int o = d.vec_gsrc[p]; f += d.stage[o]; q += d.stage[o + d.q_ofs]; }
+      f = sp_wave_sum(f); q = sp_wave_sum(q);
+      if (lane == 0) {
+        if (a.gshunt != 0.0 && !(a.dmask[e] & 2)) f += a.gshunt * d.xcur[e];
+        d.Q[e] = q;
+        const double F = f + alpha0 * q + d.hq[e];
+        d.F[e] = F; d.rhs[e] = -F;
+      }
+    }
   }
 }
 __global__ void sp_diag_shunt_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {  // gmin stepping: + gshunt on node diagonals
@@ -218,6 +259,88 @@ __global__ __launch_bounds__(1024) void sp_lu_solve_kernel(const SparseDev d0, c
   }
 }
 
+// ---- level-synchronous, multi-workgroup refactorisation and solves ------------------------------------------------------------
+// For Jacobians whose elimination levels are few and wide (a tiled array behind shared, non-ideal supply rails: ~13 levels of
+// ~1000 independent rows, plus two rail rows that collect one product per tile): one launch per level, every CU busy.
+//   factor, level l (right-looking):  A-items  l_ik = a_ik / u_kk  for the L entries whose pivot k is in level l;
+//                                     B-items  a_dst -= sum (a_ik / u_kk) * u_kc  over the level's pivots, per destination,
+//                                              in a fixed order (deterministic); long lists are reduced by a whole wavefront.
+//   forward / backward substitution by the same levels; a row with a long L part (a rail) is reduced by a wavefront.
+// Nothing is updated in place that the same launch reads (see SparsePlan), so a level needs no synchronisation inside it.
+__global__ void sp2_scatter_kernel(const SparseDev d0, const int* act) {
+  const SparseDev d = sp_pick(d0, act);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { d.flag[0] = 0; d.dflag[0] = 0; }
+  if (i >= d.nnz_lu) return;
+  const int a = d.lu2a[i];
+  d.LUv[i] = a >= 0 ? d.Aval[a] : 0.0;
+}
+__device__ __forceinline__ double sp2_wave_sum(double v) {   // fixed-order tree: deterministic
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// grid.x: [thread items: A-items then light B-items, 256 per block] then [heavy B-items, 4 wavefronts per block]
+__global__ __launch_bounds__(256) void sp2_factor_level_kernel(const SparseDev d0, const int* act, int a0, int nA, int b0, int nBl, int nBh, int thread_blocks) {
+  const SparseDev d = sp_pick(d0, act);
+  if ((int)blockIdx.x < thread_blocks) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < nA) {
+      const int p = d.la_pos[a0 + t];
+      d.Lv[p] = d.LUv[p] / d.LUv[d.la_diag[a0 + t]];
+    } else if (t < nA + nBl) {
+      const int it = b0 + (t - nA);
+      double s = 0.0;
+      for (int q = d.lb_sptr[it]; q < d.lb_sptr[it + 1]; ++q) s += (d.LUv[d.lb_l[q]] / d.LUv[d.lb_d[q]]) * d.LUv[d.lb_u[q]];
+      d.LUv[d.lb_dst[it]] -= s;
+    }
+  } else {
+    const int w = ((int)blockIdx.x - thread_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= nBh) return;
+    const int it = b0 + nBl + w;
+    double s = 0.0;
+    for (int q = d.lb_sptr[it] + lane; q < d.lb_sptr[it + 1]; q += 64) s += (d.LUv[d.lb_l[q]] / d.LUv[d.lb_d[q]]) * d.LUv[d.lb_u[q]];
+    s = sp2_wave_sum(s);
+    if (lane == 0) d.LUv[d.lb_dst[it]] -= s;
+  }
+}
+// forward substitution, one level: y_k = b(prow[k]) - sum_j l_kj y_j; also the pivot check of the level's rows
+__global__ __launch_bounds__(256) void sp2_fwd_level_kernel(const SparseDev d0, const int* act, int r0, int nl, int nh, int thread_blocks) {
+  const SparseDev d = sp_pick(d0, act);
+  if ((int)blockIdx.x < thread_blocks) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nl) return;
+    const int k = d.fl_rows[r0 + t];
+    double s = d.rhs[d.prow[k]];
+    for (int e = d.lrow_ptr[k]; e < d.lrow_ptr[k + 1]; ++e) s -= d.Lv[d.l_pos[e]] * d.y[d.l_k[e]];
+    d.y[k] = s;
+    const double ukk = d.LUv[d.diag_pos[k]];
+    if (!(fabs(ukk) > 0.0) || !(fabs(ukk) < 1e300)) { d.flag[0] = 1; d.dflag[0] = 1; }
+  } else {
+    const int w = ((int)blockIdx.x - thread_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= nh) return;
+    const int k = d.fl_rows[r0 + nl + w];
+    double s = 0.0;
+    for (int e = d.lrow_ptr[k] + lane; e < d.lrow_ptr[k + 1]; e += 64) s += d.Lv[d.l_pos[e]] * d.y[d.l_k[e]];
+    s = sp2_wave_sum(s);
+    if (lane == 0) {
+      d.y[k] = d.rhs[d.prow[k]] - s;
+      const double ukk = d.LUv[d.diag_pos[k]];
+      if (!(fabs(ukk) > 0.0) || !(fabs(ukk) < 1e300)) { d.flag[0] = 1; d.dflag[0] = 1; }
+    }
+  }
+}
+// backward substitution, one level: z_k = (y_k - sum_{j>k} u_kj z_j) / u_kk ; dx(pcol[k]) = z_k
+__global__ __launch_bounds__(256) void sp2_bwd_level_kernel(const SparseDev d0, const int* act, int r0, int nr) {
+  const SparseDev d = sp_pick(d0, act);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nr) return;
+  const int k = d.bl_rows[r0 + t];
+  double s = d.y[k];
+  for (int e = d.urow_ptr[k]; e < d.urow_ptr[k + 1]; ++e) s -= d.LUv[d.u_pos[e]] * d.dx[d.pcol[d.u_col[e]]];
+  d.dx[d.pcol[k]] = s / d.LUv[d.diag_pos[k]];
+}
+
 // reductions: red[0]=max|F|, red[1]=max|dx| over node rows, red[2]=sum (dx*w)^2, red[3]=bad flag
 __global__ __launch_bounds__(1024) void sp_norms_kernel(const NewtonArgs a, const SparseDev d0, const int* act, int what) {
   const SparseDev d = sp_pick(d0, act);
@@ -249,7 +372,18 @@ __global__ __launch_bounds__(1024) void sp_update_kernel(const NewtonArgs a, con
     const double xn = d.xcur[i] + dxi;
     if (!(xn == xn) || fabs(xn) > 1e300) sbad = 1;
     const double tt = dxi * d.w[i]; e2 += tt * tt;
-    if (a.mode == MODE_TRAN) { double q = d.Q[i]; for (int p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) q += d.Cval[p] * scale * d.dx[d.colidx[p]]; d.qn[i] = q; }
+    if (a.mode == MODE_TRAN && d.rowptr[i + 1] - d.rowptr[i] <= 256) { double q = d.Q[i]; for (int p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) q += d.Cval[p] * scale * d.dx[d.colidx[p]]; d.qn[i] = q; }
+  }
+  if (a.mode == MODE_TRAN) {   // long rows (rails): one wavefront each, lanes over the row
+    const int lane = t & 63, wv = t >> 6;
+    for (int i = wv; i < d.n; i += 16) {
+      const int r0 = d.rowptr[i], r1 = d.rowptr[i + 1];
+      if (r1 - r0 <= 256) continue;
+      double q = 0.0;
+      for (int p = r0 + lane; p < r1; p += 64) q += d.Cval[p] * scale * d.dx[d.colidx[p]];
+      q = sp_wave_sum(q);
+      if (lane == 0) d.qn[i] = d.Q[i] + q;
+    }
   }
   s2[t] = e2;
   __syncthreads();

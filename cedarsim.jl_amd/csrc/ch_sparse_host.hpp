@@ -5,6 +5,7 @@
 // AddressSanitizer (tests/test_host_analysis_fuzz.py).
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -37,8 +38,24 @@ struct SparsePlan {
   std::vector<int> upd_dst, upd_src;    // positions in LU values
   // per pivot row: its U entries (excluding the diagonal): positions and pivot-space columns
   std::vector<int> urow_ptr, u_pos, u_col;
+  // ---- level-synchronous right-looking form (the multi-workgroup kernels of ch_sparse.hpp) ----
+  // At level l every pivot of the level is final.  A-items: the L entries (i, k) with level(k) == l — l_ik = a_ik / u_kk.
+  // B-items: every position that receives updates from pivots of level l, with the list of its (l_pos, u_pos, diag_pos)
+  // source triples in a fixed order: a_dst -= sum (a[l_pos] / a[diag_pos]) * a[u_pos].  Items with long lists (a supply rail
+  // collects one product per tile) are reduced by a whole wavefront; the others by one thread.
+  std::vector<int> la_ptr, la_pos, la_diag;                 // [n_rlvl+1], per A-item
+  std::vector<int> lb_ptr;                                  // [n_rlvl+1] into the B-item arrays, light items first inside a level
+  std::vector<int> lb_nheavy;                               // [n_rlvl] heavy items of the level (they follow the light ones)
+  std::vector<int> lb_dst, lb_sptr;                         // per B-item: destination position, [items+1] into the source arrays
+  std::vector<int> lb_l, lb_u, lb_d;                        // per source: l_pos, u_pos, diag_pos
+  // triangular solves by level: rows of a level, light rows first, then heavy rows (long L rows: one wavefront each)
+  std::vector<int> fl_ptr, fl_rows, fl_nheavy;              // forward:  [n_lvl+1], rows, heavy count per level
+  std::vector<int> bl_ptr, bl_rows;                         // backward: [n_ulvl+1], rows (U rows are short here: one thread each)
+  int max_level_width = 0, n_rlvl = 0;                      // n_rlvl: levels of the factorisation (la_ptr / lb_ptr have n_rlvl + 1 entries)
+  bool wide_levels = false;                                 // true: few, wide levels — use the multi-workgroup kernels
   bool valid = false;
 };
+constexpr int SP_HEAVY = 48;   // sources per B-item / L entries per row above which a wavefront takes the item
 
 // Maximum transversal (augmenting DFS) restricted to "usable" entries; returns row_of_col or empty on failure.
 inline bool max_transversal(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<char>& usable,
@@ -171,6 +188,69 @@ inline int sparse_analyse(int n, const std::vector<int>& rowptr, const std::vect
   };
   group(level, P.lvl_ptr, P.lvl_rows);
   group(ulevel, P.ulvl_ptr, P.ulvl_rows);
+  // ---- level-synchronous form ----
+  {
+    const int nl = (int)P.lvl_ptr.size() - 1, nul = (int)P.ulvl_ptr.size() - 1;
+    // Right-looking levels: pivot k waits for every earlier pivot j that touches row k (j in the L pattern of k) OR column k
+    // (k in the U pattern of j: pivot j then updates the entries (i, k) below the diagonal).  On a structurally symmetric
+    // pattern this is the row level; circuit matrices are only nearly symmetric (controlled sources, branch rows).
+    std::vector<int> rlevel(n, 0);
+    for (int k = 0; k < n; ++k) {
+      for (int j : rowpat[k]) {
+        if (j < k) rlevel[k] = std::max(rlevel[k], rlevel[j] + 1);
+      }
+      for (int c : rowpat[k]) if (c > k) rlevel[c] = std::max(rlevel[c], rlevel[k] + 1);   // rlevel[k] is final here: all its predecessors are < k
+    }
+    int nrl = 0; for (int v : rlevel) nrl = std::max(nrl, v + 1);
+    P.n_rlvl = nrl;
+    std::vector<std::vector<std::pair<int, int>>> a_items(nrl);                 // (l_pos, diag_pos)
+    std::vector<std::map<int, std::vector<std::array<int, 3>>>> b_items(nrl);    // dst -> sources, in row / entry order
+    for (int i = 0; i < n; ++i) {
+      for (int e = P.lrow_ptr[i]; e < P.lrow_ptr[i + 1]; ++e) {
+        const int k = P.l_k[e], lk = rlevel[k];
+        a_items[lk].push_back({P.l_pos[e], P.diag_pos[k]});
+        for (int q = P.l_upd_ptr[e]; q < P.l_upd_ptr[e + 1]; ++q) b_items[lk][P.upd_dst[q]].push_back({P.l_pos[e], P.upd_src[q], P.diag_pos[k]});
+      }
+    }
+    P.la_ptr.assign(1, 0); P.la_pos.clear(); P.la_diag.clear();
+    P.lb_ptr.assign(1, 0); P.lb_nheavy.clear(); P.lb_dst.clear(); P.lb_sptr.assign(1, 0); P.lb_l.clear(); P.lb_u.clear(); P.lb_d.clear();
+    P.max_level_width = 0;
+    for (int l = 0; l < nrl; ++l) {
+      for (auto& it : a_items[l]) { P.la_pos.push_back(it.first); P.la_diag.push_back(it.second); }
+      P.la_ptr.push_back((int)P.la_pos.size());
+      int nheavy = 0;
+      for (int pass = 0; pass < 2; ++pass)   // light items first, heavy ones after them
+        for (auto& kv : b_items[l]) {
+          const bool heavy = (int)kv.second.size() > SP_HEAVY;
+          if (heavy != (pass == 1)) continue;
+          nheavy += heavy ? 1 : 0;
+          P.lb_dst.push_back(kv.first);
+          for (auto& sx : kv.second) { P.lb_l.push_back(sx[0]); P.lb_u.push_back(sx[1]); P.lb_d.push_back(sx[2]); }
+          P.lb_sptr.push_back((int)P.lb_l.size());
+        }
+      P.lb_ptr.push_back((int)P.lb_dst.size());
+      P.lb_nheavy.push_back(nheavy);
+    }
+    for (int l = 0; l < nl; ++l) P.max_level_width = std::max(P.max_level_width, P.lvl_ptr[l + 1] - P.lvl_ptr[l]);
+    P.fl_ptr.assign(1, 0); P.fl_rows.clear(); P.fl_nheavy.clear();
+    for (int l = 0; l < nl; ++l) {
+      int nheavy = 0;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int r = P.lvl_ptr[l]; r < P.lvl_ptr[l + 1]; ++r) {
+          const int k = P.lvl_rows[r];
+          const bool heavy = P.lrow_ptr[k + 1] - P.lrow_ptr[k] > SP_HEAVY;
+          if (heavy != (pass == 1)) continue;
+          nheavy += heavy ? 1 : 0;
+          P.fl_rows.push_back(k);
+        }
+      P.fl_ptr.push_back((int)P.fl_rows.size());
+      P.fl_nheavy.push_back(nheavy);
+    }
+    P.bl_ptr = P.ulvl_ptr; P.bl_rows = P.ulvl_rows;
+    // worth a launch per level only when the levels are few and wide (a tiled array behind shared rails: 13 levels of ~1000
+    // rows); a chain (RC ladder: one row per level) stays on the single-workgroup kernel
+    P.wide_levels = nrl + nl + nul <= 144 && 3 * n >= 8 * (nrl + nl + nul);
+  }
   P.valid = true;
   return CH_OK;
 }

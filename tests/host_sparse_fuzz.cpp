@@ -105,6 +105,38 @@ int main() {
           for (int i = 0; i < n; ++i) { if (!std::isfinite(dx[i])) finite = false; err = std::max(err, std::fabs(dx[i] - xr[i])); nrm = std::max(nrm, std::fabs(xr[i])); }
           // static pivots chosen from |a| >= 1e-3 * row max can lose ~3 digits against partial pivoting; more is a plan bug
           if (finite) { ++nreplay; worst = std::max(worst, err / nrm); if (err / nrm > 1e-5) { printf("replay mismatch n=%d err=%g\n", n, err / nrm); ++nfail; } }
+          // the level-synchronous form (sp2_* kernels): A-items and B-items level by level, then the solves with the scaled L
+          if (finite) {
+            std::vector<double> a2(P.nnz_lu, 0.0), Lv(P.nnz_lu, 0.0), y2(n, 0.0), z2(n, 0.0);
+            for (size_t i = 0; i < ci.size(); ++i) a2[P.a2lu[i]] = av[i];
+            const int nl = (int)P.lvl_ptr.size() - 1;
+            for (int l = 0; l < P.n_rlvl; ++l) {
+              std::vector<double> before = a2;   // a launch reads only values no item of the same launch writes: check it
+              for (int t = P.la_ptr[l]; t < P.la_ptr[l + 1]; ++t) Lv[P.la_pos[t]] = before[P.la_pos[t]] / before[P.la_diag[t]];
+              for (int it = P.lb_ptr[l]; it < P.lb_ptr[l + 1]; ++it) {
+                double s2 = 0;
+                for (int q = P.lb_sptr[it]; q < P.lb_sptr[it + 1]; ++q) {
+                  if (a2[P.lb_l[q]] != before[P.lb_l[q]] || a2[P.lb_u[q]] != before[P.lb_u[q]] || a2[P.lb_d[q]] != before[P.lb_d[q]]) { printf("level %d reads a value it also writes\n", l); ++nfail; }
+                  s2 += (before[P.lb_l[q]] / before[P.lb_d[q]]) * before[P.lb_u[q]];
+                }
+                a2[P.lb_dst[it]] -= s2;
+              }
+              if (P.lb_ptr[l + 1] - P.lb_ptr[l] < P.lb_nheavy[l]) { printf("heavy count\n"); ++nfail; }
+            }
+            for (int l = 0; l < nl; ++l) for (int r = P.fl_ptr[l]; r < P.fl_ptr[l + 1]; ++r) {
+              const int k = P.fl_rows[r]; double s2 = b[P.prow[k]];
+              for (int e = P.lrow_ptr[k]; e < P.lrow_ptr[k + 1]; ++e) s2 -= Lv[P.l_pos[e]] * y2[P.l_k[e]];
+              y2[k] = s2;
+            }
+            for (size_t l = 0; l + 1 < P.bl_ptr.size(); ++l) for (int r = P.bl_ptr[l]; r < P.bl_ptr[l + 1]; ++r) {
+              const int k = P.bl_rows[r]; double s2 = y2[k];
+              for (int e = P.urow_ptr[k]; e < P.urow_ptr[k + 1]; ++e) s2 -= a2[P.u_pos[e]] * z2[P.pcol[P.u_col[e]]];
+              z2[P.pcol[k]] = s2 / a2[P.diag_pos[k]];
+            }
+            double e2 = 0;
+            for (int i = 0; i < n; ++i) e2 = std::max(e2, std::fabs(z2[i] - dx[i]));
+            if (!(e2 <= 1e-9 * nrm + 1e-300)) { printf("level-synchronous replay differs from the row-wise one: n=%d err=%g\n", n, e2 / nrm); ++nfail; }
+          }
         }
       }
     }
