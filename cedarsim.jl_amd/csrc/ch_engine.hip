@@ -249,7 +249,8 @@ struct ch_circuit {
   struct PlanDev { DevBuf<int> prow, pcol, a2lu, diag_pos, lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows, lrow_ptr, l_pos, l_k, l_upd_ptr, upd_dst, upd_src, urow_ptr, u_pos, u_col;
                    DevBuf<int> lu2a, la_pos, la_diag, lb_dst, lb_sptr, lb_l, lb_u, lb_d, fl_rows, bl_rows; DevBuf<double> LUv, Lv; } plan_dev[2];
   DevBuf<int> sp_dflag;
-  DevBuf<int> sp_rowptr, sp_colidx, sp_mat_gptr, sp_mat_gsrc, sp_vec_gptr, sp_vec_gsrc;
+  DevBuf<int> sp_rowptr, sp_colidx, sp_mat_gptr, sp_mat_gsrc, sp_vec_gptr, sp_vec_gsrc, sp_heavy_mat, sp_heavy_vec, sp_heavy_rows;
+  int n_heavy_mat = 0, n_heavy_vec = 0, n_heavy_rows = 0;
   DevBuf<double> sp_stage, sp_Aval, sp_Cval, sp_F, sp_Q, sp_rhs, sp_y, sp_dx, sp_xcur, sp_xpred, sp_hq, sp_w, sp_qn;
   std::vector<int> h_rowptr, h_colidx;
   double* h_red = nullptr; int* h_flag = nullptr;  // mapped pinned: [S][8], [S][2]
@@ -626,6 +627,15 @@ struct ch_circuit {
       vgs.insert(vgs.end(), vrows[i].begin(), vrows[i].end()); vgp.push_back((int)vgs.size());
     }
     const size_t nnz = h_colidx.size();
+    { std::vector<int> hm, hv;
+      for (size_t i = 0; i < nnz; ++i) if (mgp[i + 1] - mgp[i] > SP_ASM_HEAVY) hm.push_back((int)i);
+      for (int i = 0; i < n; ++i) if (vgp[i + 1] - vgp[i] > SP_ASM_HEAVY) hv.push_back(i);
+      n_heavy_mat = (int)hm.size(); n_heavy_vec = (int)hv.size();
+      HIPCHK(sp_heavy_mat.upload(hm, st)); HIPCHK(sp_heavy_vec.upload(hv, st));
+      std::vector<int> hr;
+      for (int i = 0; i < n; ++i) if (h_rowptr[i + 1] - h_rowptr[i] > 256) hr.push_back(i);
+      n_heavy_rows = (int)hr.size();
+      HIPCHK(sp_heavy_rows.upload(hr, st)); }
     HIPCHK(sp_rowptr.upload(h_rowptr, st)); HIPCHK(sp_colidx.upload(h_colidx, st)); HIPCHK(sp_mat_gptr.upload(mgp, st)); HIPCHK(sp_mat_gsrc.upload(mgs, st));
     HIPCHK(sp_vec_gptr.upload(vgp, st)); HIPCHK(sp_vec_gsrc.upload(vgs, st));
     HIPCHK(sp_stage.alloc((size_t)S * nd * A.stride())); HIPCHK(sp_Aval.alloc((size_t)S * nnz)); HIPCHK(sp_Cval.alloc((size_t)S * nnz));
@@ -652,6 +662,8 @@ struct ch_circuit {
     d.upd_dst = pd.upd_dst.p; d.upd_src = pd.upd_src.p; d.urow_ptr = pd.urow_ptr.p; d.u_pos = pd.u_pos.p; d.u_col = pd.u_col.p;
     d.lu2a = pd.lu2a.p; d.la_pos = pd.la_pos.p; d.la_diag = pd.la_diag.p; d.lb_dst = pd.lb_dst.p; d.lb_sptr = pd.lb_sptr.p; d.lb_l = pd.lb_l.p; d.lb_u = pd.lb_u.p; d.lb_d = pd.lb_d.p;
     d.fl_rows = pd.fl_rows.p; d.bl_rows = pd.bl_rows.p;
+    d.heavy_rows = sp_heavy_rows.p; d.n_heavy_rows = n_heavy_rows;
+    d.heavy_mat = sp_heavy_mat.p; d.heavy_vec = sp_heavy_vec.p; d.n_heavy_mat = n_heavy_mat; d.n_heavy_vec = n_heavy_vec;
     d.Lv = pd.Lv.p ? pd.Lv.p + (size_t)sm * (size_t)std::max(0, P.nnz_lu) : nullptr;
     d.s = sm; d.xofs = (long)sm * (long)n;
     d.st_stage = (long)(nd * A.stride()); d.st_nnz = (long)nnz; d.st_lu = (long)std::max(0, P.nnz_lu); d.st_n = (long)n;
@@ -709,7 +721,7 @@ struct ch_circuit {
     }
     for (int l = 0; l < nl; ++l) {
       const int nr = P.fl_ptr[l + 1] - P.fl_ptr[l], nh = P.fl_nheavy[l], nlg = nr - nh;
-      const int tb = (nlg + 255) / 256, hb = (nh + 3) / 4;
+      const int tb = (nlg + 255) / 256, hb = nh;   // one workgroup per heavy row
       hipLaunchKernelGGL(sp2_fwd_level_kernel, dim3((unsigned)std::max(1, tb + hb), ny), dim3(256), 0, st, d, wl, P.fl_ptr[l], nlg, nh, tb);
     }
     for (int l = 0; l < nul; ++l) {
@@ -799,6 +811,7 @@ struct ch_circuit {
         const SparseDev d = sparse_dev(which); const int* al = sp_act[1].p;
         hipLaunchKernelGGL(sp_eval_kernel, grid(gd, act.size()), dim3(64), 0, st, a, d, al);
         hipLaunchKernelGGL(sp_assemble_kernel, grid(ga, act.size()), b256, 0, st, a, d, al);
+        if (n_heavy_mat + n_heavy_vec > 0) hipLaunchKernelGGL(sp_assemble_heavy_kernel, grid(n_heavy_mat + n_heavy_vec, act.size()), b256, 0, st, a, d, al);
         if (a.gshunt != 0.0) hipLaunchKernelGGL(sp_diag_shunt_kernel, grid(gn, act.size()), b256, 0, st, a, d, al);
         if (a.mode == MODE_DC) hipLaunchKernelGGL(sp_norms_kernel, grid(1, act.size()), b1k, 0, st, a, d, al, 0);
         n_launch += 2;

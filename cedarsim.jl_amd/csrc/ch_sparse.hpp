@@ -39,6 +39,8 @@ struct SparseDev {
   // level-synchronous form (multi-workgroup kernels)
   const int* lu2a; const int* la_pos; const int* la_diag; const int* lb_dst; const int* lb_sptr; const int* lb_l; const int* lb_u; const int* lb_d;
   const int* fl_rows; const int* bl_rows; double* Lv;
+  const int* heavy_rows; int n_heavy_rows;   // CSR rows with more than 256 entries
+  const int* heavy_mat; const int* heavy_vec; int n_heavy_mat, n_heavy_vec;   // CSR entries / rows with more than SP_ASM_HEAVY gather sources
   int n, nnz, nnz_lu, n_lvl, n_ulvl, n_dev;
   int s; long xofs;                // sample handled by this workgroup; its offset s*n inside a slot of the state ring
   long st_stage, st_nnz, st_lu, st_n;  // per-sample strides of the work arrays (the struct is built for sample 0)
@@ -149,32 +151,22 @@ __device__ __forceinline__ double sp_wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+constexpr int SP_ASM_HEAVY = 64;
 __global__ __launch_bounds__(256) void sp_assemble_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
   const SparseDev d = sp_pick(d0, act);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wbase = i - lane;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
-  {
-    const int p0 = i < d.nnz ? d.mat_gptr[i] : 0, p1 = i < d.nnz ? d.mat_gptr[i + 1] : 0;
-    const bool heavy = p1 - p0 > 64;
-    if (i < d.nnz && !heavy) {
+  if (i < d.nnz) {
+    const int p0 = d.mat_gptr[i], p1 = d.mat_gptr[i + 1];
+    if (p1 - p0 <= SP_ASM_HEAVY) {
       double g = 0.0, c = 0.0;
       for (int p = p0; p < p1; ++p) { const int o = d.mat_gsrc[p]; g += d.stage[o]; c += d.stage[o + d.c_ofs]; }
       d.Aval[i] = g + alpha0 * c; d.Cval[i] = c;
     }
-    unsigned long long hm = __ballot(heavy);
-    while (hm) {
-      const int l = __ffsll((long long)hm) - 1; hm &= hm - 1;
-      const int e = wbase + l;
-      double g = 0.0, c = 0.0;
-      for (int p = d.mat_gptr[e] + lane; p < d.mat_gptr[e + 1]; p += 64) { const int o = d.mat_gsrc[p]; g += d.stage[o]; c += d.stage[o + d.c_ofs]; }
-      g = sp_wave_sum(g); c = sp_wave_sum(c);
-      if (lane == 0) { d.Aval[e] = g + alpha0 * c; d.Cval[e] = c; }
-    }
   }
-  {
-    const int p0 = i < d.n ? d.vec_gptr[i] : 0, p1 = i < d.n ? d.vec_gptr[i + 1] : 0;
-    const bool heavy = p1 - p0 > 64;
-    if (i < d.n && !heavy) {
+  if (i < d.n) {
+    const int p0 = d.vec_gptr[i], p1 = d.vec_gptr[i + 1];
+    if (p1 - p0 <= SP_ASM_HEAVY) {
       double f = 0.0, q = 0.0;
       for (int p = p0; p < p1; ++p) { const int o = d.vec_gsrc[p]; f += d.stage[o]; q += d.stage[o + d.q_ofs]; }
       if (a.gshunt != 0.0 && !(a.dmask[i] & 2)) f += a.gshunt * d.xcur[i];
@@ -182,20 +174,47 @@ __global__ __launch_bounds__(256) void sp_assemble_kernel(const NewtonArgs a, co
       const double F = f + alpha0 * q + d.hq[i];
       d.F[i] = F; d.rhs[i] = -F;
     }
-    unsigned long long hm = __ballot(heavy);
-    while (hm) {
-      const int l = __ffsll((long long)hm) - 1; hm &= hm - 1;
-      const int e = wbase + l;
-      double f = 0.0, q = 0.0;
-      for (int p = d.vec_gptr[e] + lane; p < d.vec_gptr[e + 1]; p += 64) { const int o = d.vec_gsrc[p]; f += d.stage[o]; q += d.stage[o + d.q_ofs]; }
-      f = sp_wave_sum(f); q = sp_wave_sum(q);
-      if (lane == 0) {
-        if (a.gshunt != 0.0 && !(a.dmask[e] & 2)) f += a.gshunt * d.xcur[e];
-        d.Q[e] = q;
-        const double F = f + alpha0 * q + d.hq[e];
-        d.F[e] = F; d.rhs[e] = -F;
-      }
-    }
+  }
+}
+// fixed-order block reduction of two values (256 threads): wave trees, then the four wave results in order
+__device__ __forceinline__ void sp_block_sum2(double& x, double& y, double* sh) {
+  x = sp_wave_sum(x); y = sp_wave_sum(y);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { sh[wv] = x; sh[4 + wv] = y; }
+  __syncthreads();
+  x = ((sh[0] + sh[1]) + sh[2]) + sh[3]; y = ((sh[4] + sh[5]) + sh[6]) + sh[7];
+}
+// the entries and rows with long gather lists (a supply rail shared by every tile collects one stamp per attached device): one
+// 256-thread workgroup per item, four sources in flight per thread, fixed-order reduction — deterministic like the light path
+__global__ __launch_bounds__(256) void sp_assemble_heavy_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
+  const SparseDev d = sp_pick(d0, act);
+  __shared__ double sh[8];
+  const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
+  const int item = blockIdx.x, t = threadIdx.x;
+  const bool vec = item >= d.n_heavy_mat;
+  const int e = vec ? d.heavy_vec[item - d.n_heavy_mat] : d.heavy_mat[item];
+  const int* gp = vec ? d.vec_gptr : d.mat_gptr; const int* gs = vec ? d.vec_gsrc : d.mat_gsrc;
+  const int off2 = vec ? d.q_ofs : d.c_ofs;
+  const int p0 = gp[e], p1 = gp[e + 1];
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = p0 + t; p < p1; p += 4 * 256) {
+    const int l = p1 - 1;
+    const int o0 = gs[p], o1 = gs[min(p + 256, l)], o2 = gs[min(p + 512, l)], o3 = gs[min(p + 768, l)];
+    const double a0 = d.stage[o0], b0 = d.stage[o0 + off2], a1 = d.stage[o1], b1 = d.stage[o1 + off2], a2 = d.stage[o2], b2 = d.stage[o2 + off2], a3 = d.stage[o3], b3 = d.stage[o3 + off2];
+    s1 += a0; s2 += b0;
+    if (p + 256 < p1) { s1 += a1; s2 += b1; }
+    if (p + 512 < p1) { s1 += a2; s2 += b2; }
+    if (p + 768 < p1) { s1 += a3; s2 += b3; }
+  }
+  sp_block_sum2(s1, s2, sh);
+  if (t == 0) {
+    if (vec) {
+      if (a.gshunt != 0.0 && !(a.dmask[e] & 2)) s1 += a.gshunt * d.xcur[e];
+      d.Q[e] = s2;
+      const double F = s1 + alpha0 * s2 + d.hq[e];
+      d.F[e] = F; d.rhs[e] = -F;
+    } else { d.Aval[e] = s1 + alpha0 * s2; d.Cval[e] = s2; }
   }
 }
 __global__ void sp_diag_shunt_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {  // gmin stepping: + gshunt on node diagonals
@@ -316,14 +335,16 @@ __global__ __launch_bounds__(256) void sp2_fwd_level_kernel(const SparseDev d0, 
     d.y[k] = s;
     const double ukk = d.LUv[d.diag_pos[k]];
     if (!(fabs(ukk) > 0.0) || !(fabs(ukk) < 1e300)) { d.flag[0] = 1; d.dflag[0] = 1; }
-  } else {
-    const int w = ((int)blockIdx.x - thread_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  } else {   // a row with a long L part: one workgroup, four entries in flight per thread
+    __shared__ double sh[8];
+    const int w = (int)blockIdx.x - thread_blocks, t = threadIdx.x;
     if (w >= nh) return;
     const int k = d.fl_rows[r0 + nl + w];
-    double s = 0.0;
-    for (int e = d.lrow_ptr[k] + lane; e < d.lrow_ptr[k + 1]; e += 64) s += d.Lv[d.l_pos[e]] * d.y[d.l_k[e]];
-    s = sp2_wave_sum(s);
-    if (lane == 0) {
+    const int e0 = d.lrow_ptr[k], e1 = d.lrow_ptr[k + 1];
+    double s = 0.0, dummy = 0.0;
+    for (int e = e0 + t; e < e1; e += 256) s += d.Lv[d.l_pos[e]] * d.y[d.l_k[e]];
+    sp_block_sum2(s, dummy, sh);
+    if (t == 0) {
       d.y[k] = d.rhs[d.prow[k]] - s;
       const double ukk = d.LUv[d.diag_pos[k]];
       if (!(fabs(ukk) > 0.0) || !(fabs(ukk) < 1e300)) { d.flag[0] = 1; d.dflag[0] = 1; }
@@ -374,16 +395,19 @@ __global__ __launch_bounds__(1024) void sp_update_kernel(const NewtonArgs a, con
     const double tt = dxi * d.w[i]; e2 += tt * tt;
     if (a.mode == MODE_TRAN && d.rowptr[i + 1] - d.rowptr[i] <= 256) { double q = d.Q[i]; for (int p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) q += d.Cval[p] * scale * d.dx[d.colidx[p]]; d.qn[i] = q; }
   }
-  if (a.mode == MODE_TRAN) {   // long rows (rails): one wavefront each, lanes over the row
-    const int lane = t & 63, wv = t >> 6;
-    for (int i = wv; i < d.n; i += 16) {
+  if (a.mode == MODE_TRAN) {   // long rows (rails): the whole workgroup strides over the row, fixed-order reduction
+    for (int h = 0; h < d.n_heavy_rows; ++h) {
+      const int i = d.heavy_rows[h];
       const int r0 = d.rowptr[i], r1 = d.rowptr[i + 1];
-      if (r1 - r0 <= 256) continue;
       double q = 0.0;
-      for (int p = r0 + lane; p < r1; p += 64) q += d.Cval[p] * scale * d.dx[d.colidx[p]];
-      q = sp_wave_sum(q);
-      if (lane == 0) d.qn[i] = d.Q[i] + q;
+      for (int p = r0 + t; p < r1; p += 1024) q += d.Cval[p] * scale * d.dx[d.colidx[p]];
+      __syncthreads();
+      s2[t] = q;
+      __syncthreads();
+      for (int o = 512; o > 0; o >>= 1) { if (t < o) s2[t] += s2[t + o]; __syncthreads(); }
+      if (t == 0) d.qn[i] = d.Q[i] + s2[0];
     }
+    __syncthreads();
   }
   s2[t] = e2;
   __syncthreads();

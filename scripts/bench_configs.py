@@ -70,7 +70,7 @@ if only in ("all", "config4_share"):
     out["config4_share_mc1024"] = {"samples": S, "note": "the per-GPU share of the 8192-sample Monte-Carlo on an 8-GPU node", **res}
 if only in ("all", "coupled"):
     # config 3 with non-ideal rails: ONE coupled block (sparse path: CSR assembly + level-scheduled LU refactor + solves)
-    for tiles in (64, 256, 1024):
+    for tiles in [int(x) for x in os.environ.get("CEDARHIP_COUPLED_TILES", "64,256,1024").split(",")]:
         c = dff_array(tiles, observe="q0", supply_r=1.0)
         e = EngineCircuit(c)
         opts = tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-12), saveat=np.array(DFF_CHECK_TIMES))
