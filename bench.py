@@ -92,6 +92,20 @@ def cpu_baseline(seconds_single=5.0, seconds_multi=10.0, seconds_proxy=5.0):
             "single_core_value": tile_rate_1 / N_TILES, "seconds_per_tile_transient_single_core": el1 / reps1}
 
 
+def combine_ranks(dist, world, device, iters, el, gate_ok, q):
+    """The only collective of the bench: one all_gather of a small per-rank vector AFTER the timed region (RCCL over xGMI when
+    `device` is a GPU, gloo on the CPU rehearsal).  Returns whole-job iterations (sum over ranks), the slowest rank's time
+    (max), the AND of the ranks' gates, and every rank's gate values."""
+    import torch
+    if dist is None or world <= 1:
+        return float(iters), el, bool(gate_ok), [list(q)]
+    buf = torch.tensor([float(iters), el, float(gate_ok)] + list(q), dtype=torch.float64, device=device)
+    out = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)  # result gather only (SURVEY 8(e))
+    res = torch.stack(out).cpu().numpy()
+    return float(res[:, 0].sum()), float(res[:, 1].max()), bool(res[:, 2].min() > 0.5), res[:, 3:].tolist()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,17 +201,7 @@ def main():
     # correctness gate of the reference harness (benchmarks/gf180_dff_solver_bench.jl:84-96)
     gate_ok = all(abs(a - b) <= 10 * TOL for a, b in zip(q, DFF_CHECK_Q))
 
-    tot_iters, max_el = float(iters), el
-    all_q = [q]
-    if dist is not None:
-        buf = torch.tensor([float(iters), el, float(gate_ok)] + q, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        out = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(out, buf)  # RCCL over xGMI: result gather only
-        res = torch.stack(out).cpu().numpy()
-        tot_iters = float(res[:, 0].sum())
-        max_el = float(res[:, 1].max())
-        gate_ok = bool(res[:, 2].min() > 0.5)
-        all_q = res[:, 3:].tolist()
+    tot_iters, max_el, gate_ok, all_q = combine_ranks(dist, world, "cuda" if backend == "nccl" else "cpu", iters, el, gate_ok, q)
 
     if rank == 0:
         nc, n_mos = info["max_component"], MOS_PER_TILE

@@ -330,55 +330,95 @@ class CircuitSweep:
     def __len__(self):
         return len(self.points)
 
-    def _batch(self, lo, hi):
-        """Base circuit + slots + per-sample values for points lo..hi (found by diffing flat tables)."""
-        base = self._build(**self.points[lo])
-        circuits = [base] + [self._build(**p) for p in self.points[lo + 1:hi]]
-        for c in circuits[1:]:
-            if c.dev_kind != base.dev_kind or c.dev_node != base.dev_node or c.dev_ipar != base.dev_ipar:
-                raise CedarError("sweep points must not change the circuit topology")
-        slots, values = [], []
-
-        def add(slot, vals):
-            slots.append(slot)
-            values.append(vals)
-
+    @staticmethod
+    def _flat(c):
+        """Every sweepable entry of a circuit's tables as one vector, with the engine slot (kind, a, b) of each position."""
         from .circuit import (SLOT_DEV_MULT, SLOT_DEV_PAR, SLOT_GMIN, SLOT_MODEL_PAR, SLOT_SRC_DC, SLOT_SRC_PAR, SLOT_TEMP, SLOT_VA_PAR)
-        par = np.array([c.dev_par for c in circuits], float)          # [P][ndev][8]
-        mult = np.array([c.dev_mult for c in circuits], float)
-        differs = lambda a: np.any((a != a[0]) & ~(np.isnan(a) & np.isnan(a[0])), axis=0)
-        if par.size:
-            dm = differs(par)
-            for d, k in zip(*np.nonzero(dm)):
-                add((SLOT_DEV_PAR, int(d), int(k)), par[:, d, k])
-            for d in np.nonzero(differs(mult))[0]:
-                add((SLOT_DEV_MULT, int(d), 0), mult[:, d])
-        sdc = np.array([[s[0] for s in c.sources] for c in circuits], float)
-        spar = np.array([[list(s[1].par) + [0.0] * (8 - len(s[1].par)) for s in c.sources] for c in circuits], float)
-        if sdc.size:
-            for i in np.nonzero(differs(sdc))[0]:
-                add((SLOT_SRC_DC, int(i), 0), sdc[:, i])
-            for i, k in zip(*np.nonzero(differs(spar))):
-                if base.sources[i][1].kind == 0 and k == 0 and any(s[0] == SLOT_SRC_DC and s[1] == i for s in slots):
-                    continue  # constant source: SRC_DC already updates the transient value
-                add((SLOT_SRC_PAR, int(i), int(k)), spar[:, i, k])
-        mods = np.array([c.models for c in circuits], float)
-        if mods.size:
-            for m, k in zip(*np.nonzero(differs(mods))):
-                add((SLOT_MODEL_PAR, int(m), int(k)), mods[:, m, k])
-        vap = np.array([c.va_par for c in circuits], float)            # compiled Verilog-A parameter blocks (resolved per point)
-        if vap.size:
-            for i in np.nonzero(differs(vap))[0]:
-                add((SLOT_VA_PAR, int(i), 0), vap[:, i])
-        temps = np.array([c.temp for c in circuits])
-        if np.any(temps != temps[0]):
-            add((SLOT_TEMP, 0, 0), temps)
-        gm = np.array([c.gmin for c in circuits])
-        if np.any(gm != gm[0]):
-            add((SLOT_GMIN, 0, 0), gm)
+        vals, keys = [], []
+        par = np.array(c.dev_par, float).reshape(len(c.dev_par), -1) if len(c.dev_par) else np.zeros((0, 8))
+        for d in range(par.shape[0]):
+            vals.extend(par[d]); keys.extend((SLOT_DEV_PAR, d, k) for k in range(par.shape[1]))
+        vals.extend(float(m) for m in c.dev_mult); keys.extend((SLOT_DEV_MULT, d, 0) for d in range(len(c.dev_mult)))
+        for i, sv in enumerate(c.sources):
+            vals.append(float(sv[0])); keys.append((SLOT_SRC_DC, i, 0))
+            pr = list(sv[1].par) + [0.0] * (8 - len(sv[1].par))
+            vals.extend(float(x) for x in pr); keys.extend((SLOT_SRC_PAR, i, k) for k in range(8))
+        for m, card in enumerate(c.models):
+            vals.extend(float(x) for x in card); keys.extend((SLOT_MODEL_PAR, m, k) for k in range(len(card)))
+        vals.extend(float(x) for x in c.va_par); keys.extend((SLOT_VA_PAR, i, 0) for i in range(len(c.va_par)))
+        vals.append(float(c.temp)); keys.append((SLOT_TEMP, 0, 0))
+        vals.append(float(c.gmin)); keys.append((SLOT_GMIN, 0, 0))
+        return np.array(vals, float), keys
+
+    def _same_topology(self, base, c):
+        if c.dev_kind != base.dev_kind or c.dev_node != base.dev_node or c.dev_ipar != base.dev_ipar:
+            raise CedarError("sweep points must not change the circuit topology")
+
+    def _batch(self, lo, hi):
+        """Base circuit + slots + per-sample values for points lo..hi, found by diffing the flat tables of built circuits.
+
+        The reference rebuilds nothing per point: `remake(prob, p=sim)` swaps a parameter struct (src/sweeps.jl:473-480).  Here
+        the netlist is rebuilt only as often as needed to learn the parameter -> table map: for a sweep whose variables act on
+        DISJOINT table entries (a product sweep over two resistors, a model parameter and a supply …) one build per distinct
+        value of each variable (sum of the axis lengths) instead of one per point (their product); the per-point tables are
+        then assembled by look-up.  Anything else (an entry that depends on two swept variables, zipped variables with as many
+        distinct values as points) takes one build per point."""
+        from .circuit import SLOT_SRC_DC, SLOT_SRC_PAR
+        pts = self.points[lo:hi]
+        base = self._build(**pts[0])
+        v0, keys = self._flat(base)
+        differs = lambda x, y: (x != y) & ~(np.isnan(x) & np.isnan(y))  # noqa: E731
+        table = None
+        names = sorted({k for p in pts for k in p})
+        if names and all(set(p) == set(names) for p in pts):
+            distinct = {k: list(dict.fromkeys(p[k] for p in pts)) for k in names}
+            if 1 + sum(len(v) - 1 for v in distinct.values()) < len(pts):
+                cols, owner, ok = {}, np.full(len(v0), -1), True
+                for ki, k in enumerate(names):
+                    for val in distinct[k]:
+                        if val == pts[0][k]:
+                            cols[(k, val)] = v0
+                            continue
+                        c = self._build(**dict(pts[0], **{k: val}))
+                        self._same_topology(base, c)
+                        vv, _ = self._flat(c)
+                        if len(vv) != len(v0):
+                            ok = False
+                            break
+                        ch = differs(vv, v0)
+                        if np.any(ch & (owner >= 0) & (owner != ki)):
+                            ok = False   # an entry that answers to two variables: not separable
+                            break
+                        owner[ch] = ki
+                        cols[(k, val)] = vv
+                    if not ok:
+                        break
+                if ok:
+                    table = np.tile(v0, (len(pts), 1))
+                    for ki, k in enumerate(names):
+                        idx = np.nonzero(owner == ki)[0]
+                        if len(idx):
+                            for r, p in enumerate(pts):
+                                table[r, idx] = cols[(k, p[k])][idx]
+        if table is None:
+            rows = [v0]
+            for p in pts[1:]:
+                c = self._build(**p)
+                self._same_topology(base, c)
+                vv, _ = self._flat(c)
+                if len(vv) != len(v0):
+                    raise CedarError("sweep points must not change the circuit topology")
+                rows.append(vv)
+            table = np.array(rows)
+        ch = np.nonzero(np.any(differs(table, table[0:1]), axis=0))[0]
+        slots = [keys[i] for i in ch]
+        # a constant source whose dc is swept: SRC_DC already updates the transient value
+        drop = {i for i in ch if keys[i][0] == SLOT_SRC_PAR and keys[i][2] == 0 and base.sources[keys[i][1]][1].kind == 0 and (SLOT_SRC_DC, keys[i][1], 0) in slots}
+        ch = [i for i in ch if i not in drop]
+        slots = [keys[i] for i in ch]
         base.slots = list(slots)
         base.slot_names = [("slot%d" % i, None) for i in range(len(slots))]
-        return base, list(range(len(slots))), np.array(values, float).reshape(len(slots), hi - lo)
+        return base, list(range(len(slots))), np.ascontiguousarray(table[:, ch].T, float).reshape(len(slots), hi - lo)
 
     def _run(self, kind, kw, ctx):
         lo, hi = shard_range(len(self.points), self.rank, self.world)

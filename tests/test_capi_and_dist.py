@@ -84,6 +84,36 @@ def test_sharded_sweep_gathers_over_gloo_world_size_2(tmp_path, oracle_lib):
     assert "GLOO_OK" in r.stdout
 
 
+BENCH_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+import bench
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+# rank 0: 1000 iterations in 0.05 s, gate ok; rank 1: 1200 iterations in 0.07 s, gate NOT ok
+iters, el, ok = (1000, 0.05, True) if rank == 0 else (1200, 0.07, False)
+tot, mx, gate, allq = bench.combine_ranks(dist, world, "cpu", iters, el, ok, [0.0, 0.0, 5.0, 5.0, 5.0 - rank])
+assert tot == 2200.0 and mx == 0.07 and gate is False and len(allq) == 2 and allq[1][4] == 4.0
+tot, mx, gate, _ = bench.combine_ranks(dist, world, "cpu", iters, el, True, [0.0] * 5)
+assert gate is True and abs(tot / mx - 2200.0 / 0.07) < 1e-9
+if rank == 0: print("BENCH_COMBINE_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_bench_line_sums_ranks_and_ands_the_gates_over_gloo(tmp_path):
+    """bench.py --gpus N: `value` is the whole-job rate (sum of the ranks' iterations over the slowest rank's time) and the
+    reference gate must hold on EVERY rank — the aggregation function of bench.py under a 2-rank gloo group."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "BENCH_COMBINE_OK" in r.stdout
+
+
 def _build_c_demo(tmp_path):
     from cedarsim_jl_amd import engine
     exe = str(tmp_path / "c_abi_demo")

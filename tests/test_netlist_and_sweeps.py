@@ -170,3 +170,46 @@ def test_solution_call_interpolates_with_pchip():
     lin = np.abs(np.interp(tq, t, np.sin(6 * t)) - np.sin(6 * tq)).max()
     assert err < 6e-3 and err < 0.6 * lin
     assert isinstance(sol(0.5, idxs="node_a"), float) and len(sol(0.5, idxs=["node_a"])) == 1
+
+
+def test_sweep_batch_learns_the_parameter_map_from_few_builds():
+    """CircuitSweep._batch (the host half of `remake(prob, p=sim)` over a sweep, src/sweeps.jl:471-482): a product sweep whose
+    variables act on disjoint table entries is assembled from one build per distinct axis value (20 + 20 - 1 = 39 builds for
+    the reference's 400-point sweep, test/sweep.jl:326-340), a sweep with a coupled entry falls back to one build per point,
+    and both give the per-point tables exactly."""
+    import numpy as np
+    from cedarsim_jl_amd import Circuit, CircuitSweep, ProductSweep, TandemSweep, frange
+    count = {"n": 0}
+
+    def two_resistor(R1=100.0, R2=100.0):
+        count["n"] += 1
+        c = Circuit()
+        c.V("V", "vcc", 0, dc=1.0)
+        c.R("R1", "vcc", "mid", R1)
+        c.R("R2", "mid", 0, R2)
+        return c
+
+    cs = CircuitSweep(two_resistor, ProductSweep(R1=frange(100.0, 100.0, 2000.0), R2=frange(100.0, 100.0, 2000.0)))
+    base, ids, vals = cs._batch(0, 400)
+    assert count["n"] == 39 and vals.shape == (2, 400) and len(base.slots) == 2
+    r1 = [p["R1"] for p in cs]
+    r2 = [p["R2"] for p in cs]
+    by_slot = {s[1]: vals[i] for i, s in enumerate(base.slots)}
+    assert np.array_equal(by_slot[base.dev_names.index("r1")], r1) and np.array_equal(by_slot[base.dev_names.index("r2")], r2)
+
+    def coupled(a=1.0, b=1.0):   # one resistor answers to both variables: not separable
+        count["n"] += 1
+        c = Circuit()
+        c.V("V", "vcc", 0, dc=1.0)
+        c.R("R", "vcc", 0, a * b)
+        return c
+
+    count["n"] = 0
+    cs2 = CircuitSweep(coupled, ProductSweep(a=[1.0, 2.0, 3.0, 4.0], b=[1.0, 10.0, 100.0, 1000.0]))
+    base2, _, vals2 = cs2._batch(0, 16)
+    assert vals2.shape == (1, 16) and np.array_equal(vals2[0], [p["a"] * p["b"] for p in cs2])
+    assert count["n"] > 16   # the separable attempt was abandoned, then one build per point
+    count["n"] = 0
+    cs3 = CircuitSweep(two_resistor, TandemSweep(R1=[1.0, 2.0, 3.0], R2=[4.0, 5.0, 6.0]))   # zipped: as many values as points
+    base3, _, vals3 = cs3._batch(0, 3)
+    assert count["n"] == 3 and vals3.shape == (2, 3)
