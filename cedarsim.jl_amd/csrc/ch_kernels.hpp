@@ -234,44 +234,101 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
   if (WIDE) widen_stamp(st, st_final);
 }
 
-// One HALF of a narrow slot's evaluation, for the wave pairs of the device-resident stepper (ch_persist.hpp): a BSIM4
-// instance is split by FUNCTION — PART 0 = threshold / mobility / drain current / output resistance / substrate and junction
-// currents (the I and G entries of the record), PART 1 = the same threshold front end, then the capMod-2 intrinsic charges,
-// junction and overlap charges (Q and C entries).  The value path dominates the model (r01_notes: 3 -> 1 derivative directions
-// removes 1 000 of 6 300 instructions), so the split is along outputs, not along derivative directions: the compiler drops
-// what a half does not store (3 925 and 3 395 instructions against 6 289).  Linear devices are evaluated whole by PART 0.
+// What one lane of the device-resident stepper evaluates, loaded ONCE per transient: a lane keeps its device for the whole time
+// span, so the device tables are not read again inside the time loop (in the per-attempt kernel they cost a chain of three
+// dependent global loads per evaluation, and seven table pointers held in scalar registers across the BSIM4 code).
+struct SlotMeta {
+  int kind;       // engine device kind, or 0 for an idle lane
+  int dl;         // device index inside the block (its stamp record)
+  int t[4];       // terminals: >= 0 block-local unknown, < 0: -(known index + 1)
+  int cls, src;   // BSIM4 class inside the block's column list; device source slot
+  double m, par;  // multiplier; first parameter of a linear device
+};
+__device__ __forceinline__ SlotMeta load_slot_meta(const EvalCtx& a, int s, int dofs, int uofs, int slot) {
+  SlotMeta q;
+  q.kind = 0; q.dl = 0; q.cls = 0; q.src = 0; q.m = 0.0; q.par = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q.t[k] = -1;
+  if (slot < 0) return q;
+  const int dl = slot >> 4, d = dofs + dl;
+  q.dl = dl; q.kind = a.dkind[d];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int t = a.dterm[NTERM * d + k]; q.t[k] = t >= 0 ? t - uofs : t; }
+  const long pi = (long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0);
+  q.m = a.dmult[pi]; q.par = a.dpar[pi]; q.cls = a.dcls_local[d]; q.src = a.dsrc[d];
+  return q;
+}
+// One HALF (or, PART < 0, the whole) of a narrow slot's evaluation from cached metadata.  For the wave pairs of the
+// device-resident stepper (ch_persist.hpp) a BSIM4 instance is split by FUNCTION — PART 0 = threshold / mobility / drain current /
+// output resistance / substrate and junction currents (the I and G entries of the record), PART 1 = the same threshold front end,
+// then the capMod-2 intrinsic charges, junction and overlap charges (Q and C entries).  The value path dominates the model
+// (r01_notes: 3 -> 1 derivative directions removes 1 000 of 6 300 instructions), so the split is along outputs, not along
+// derivative directions: the compiler drops what a half does not store (3 925 and 3 395 instructions against 6 289).  Linear
+// devices are evaluated whole by PART 0.
 template <int PART>
-__device__ __forceinline__ void eval_slot_part(const EvalCtx a, int s, int dofs, int slot, const double* xl, int uofs,
-                                               const double* kvl, const double* svl, const double* pl, double* stage) {
-  const int dl = slot >> 4;
-  const int d = dofs + dl;
-  double* st = stage + (size_t)dl * StampLayout<false>::STRIDE;
-  const int kind = a.dkind[d];
-  if (PART == 1 && kind != K_MOS) return;
-  const int* tm = a.dterm + NTERM * d;
+__device__ __forceinline__ void eval_cached(const SlotMeta& q, double gmin, const double* xl, const double* kvl, const double* svl, const double* pl, double* stage) {
+  if (q.kind == 0 || (PART == 1 && q.kind != K_MOS)) return;
+  double* st = stage + (size_t)q.dl * StampLayout<false>::STRIDE;
   double v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { const int t = tm[k]; v[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
-  const long pi = (long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0);
-  const double m = a.dmult[pi];
-  if (kind == K_MOS) {
-    const B4Col P{pl + (size_t)a.dcls_local[d] * B4L_STRIDE};
+  for (int k = 0; k < 4; ++k) v[k] = q.t[k] >= 0 ? xl[q.t[k]] : kvl[-q.t[k] - 1];
+  if (q.kind == K_MOS) {
+    const B4Col P{pl + (size_t)q.cls * B4L_STRIDE};
     double o[40];
-    b4_device(P, v[0], v[1], v[2], v[3], a.gmin, o);
-    if (PART == 0) {
+    b4_device(P, v[0], v[1], v[2], v[3], gmin, o);
+    if (PART != 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) st[j] = m * o[j];
+      for (int j = 0; j < 4; ++j) st[j] = q.m * o[j];
 #pragma unroll
-      for (int j = 8; j < 24; ++j) st[j] = m * o[j];
-    } else {
+      for (int j = 8; j < 24; ++j) st[j] = q.m * o[j];
+    }
+    if (PART != 0) {
 #pragma unroll
-      for (int j = 4; j < 8; ++j) st[j] = m * o[j];
+      for (int j = 4; j < 8; ++j) st[j] = q.m * o[j];
 #pragma unroll
-      for (int j = 24; j < 40; ++j) st[j] = m * o[j];
+      for (int j = 24; j < 40; ++j) st[j] = q.m * o[j];
     }
     return;
   }
-  eval_linear(a, kind, d, pi, m, v, svl, st);
+  const double m = q.m;
+  switch (q.kind) {
+    case K_R: {
+      const double g = m / q.par, i = g * (v[0] - v[1]);
+      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
+      st[8] = g; st[9] = -g; st[12] = -g; st[13] = g;
+      st[24] = 0.0; st[25] = 0.0; st[28] = 0.0; st[29] = 0.0;
+    } break;
+    case K_C: {
+      const double c = m * q.par, qq = c * (v[0] - v[1]);
+      st[0] = 0.0; st[1] = 0.0; st[4] = qq; st[5] = -qq;
+      st[8] = 0.0; st[9] = 0.0; st[12] = 0.0; st[13] = 0.0;
+      st[24] = c; st[25] = -c; st[28] = -c; st[29] = c;
+    } break;
+    case K_I: {
+      const double i = m * svl[q.src];
+      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
+    } break;
+    case K_V: case K_L: case K_VCVS_A: {
+      const double ib = v[2];
+      const double src = q.kind == K_V ? svl[q.src] : 0.0;
+      const double l = q.kind == K_L ? q.par : 0.0;
+      st[0] = m * ib; st[1] = -m * ib; st[2] = v[0] - v[1] - src;
+      st[4] = 0.0; st[5] = 0.0; st[6] = -l * ib;
+      st[8 + 2] = m; st[8 + 6] = -m; st[8 + 8] = 1.0; st[8 + 9] = -1.0; st[8 + 10] = 0.0;
+      st[24 + 2] = 0.0; st[24 + 6] = 0.0; st[24 + 8] = 0.0; st[24 + 9] = 0.0; st[24 + 10] = -l;
+    } break;
+    case K_VCVS_B: {
+      const double g = q.par;
+      st[0] = -g * (v[1] - v[2]); st[4] = 0.0;
+      st[8 + 1] = -g; st[8 + 2] = g; st[24 + 1] = 0.0; st[24 + 2] = 0.0;
+    } break;
+    case K_VCCS: {
+      const double g = m * q.par, i = g * (v[2] - v[3]);
+      st[0] = i; st[1] = -i; st[4] = 0.0; st[5] = 0.0;
+      st[8 + 2] = g; st[8 + 3] = -g; st[8 + 6] = -g; st[8 + 7] = g;
+      st[24 + 2] = 0.0; st[24 + 3] = 0.0; st[24 + 6] = 0.0; st[24 + 7] = 0.0;
+    } break;
+  }
 }
 
 // ---- DPP reductions over the 16-lane rows of a wavefront (no LDS round trip, ~8 cycles a step) ----

@@ -332,7 +332,7 @@ __device__ __forceinline__ double p_coef(double tau0, const double* tsl, int hea
 // LDS per workgroup: [consts: cd doubles | ci ints] [part PW*8 | summ 8] [PW wave regions]
 // wave region (doubles): st[ndev*41] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq w qn pm pp x0 dm [11*nc] | Xh[8*nc] | Qh[8*nc] | tsl[8] | coef[48]
 //                        | kvl[nk] svl[nsrc] | pl[max_mc*B4L_STRIDE] | ints: class blob, MOS class list
-// PAIR: the two waves of a pair (2q, 2q+1) share the device evaluation of their two blocks BY FUNCTION (eval_slot_part): wave
+// PAIR: the two waves of a pair (2q, 2q+1) share the device evaluation of their two blocks BY FUNCTION (eval_cached): wave
 // 2q evaluates the current half (I, G) of every MOSFET of both blocks plus the linear devices, wave 2q+1 the charge half (Q, C);
 // each wave then gathers, factors and updates its OWN block.  The device evaluation — 45 of the 100 thousand cycles of an
 // attempt — shrinks to its longer half, with one wave per SIMD as before.  The pair meets twice per Newton iteration through
@@ -458,8 +458,15 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   __syncthreads();
 
   const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar, 300.15};
-  EvalCtx ectx_h = ectx;   // the lane's block may belong to another sample than the wave's own
-  ectx_h.gmin = a.gmin_s[a.Sgmin > 1 ? s_h : 0];
+  // this lane's device for the whole transient (block `half` of the pair when PAIR, the wave's own block otherwise)
+  const double gmin_h = a.gmin_s[a.Sgmin > 1 ? (PAIR ? s_h : s) : 0];
+  SlotMeta smeta;
+  {
+    int slot = -1;
+    if (PAIR) { const int sq = lane & 31; if (live_h && sq < cm.nslots) slot = slots_h[sq]; }
+    else if (live && lane < cm.nslots) slot = slots[lane];
+    smeta = load_slot_meta(ectx, PAIR ? s_h : s, PAIR ? dofs_h : dofs, PAIR ? uofs_h : uofs, slot);
+  }
   const int n_ent = C.n_ent();
   // this lane's entry (a known-node or device-source value): its terms, and the linear piece of up to two of them
   const int e_p0 = lane < n_ent ? C.ent_ptr()[lane] : 0, e_nt = lane < n_ent ? C.ent_ptr()[lane + 1] - e_p0 : 0;
@@ -572,20 +579,16 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
           pair_sync();                                   // both iterates (or their done flags) are in LDS
           const int d0 = pf[2], d1 = pf[3];
           if ((d0 && d1) || pair_broken) break;
-          const int sq = lane & 31;
-          if (live_h && !(half ? d1 : d0) && sq < cm.nslots) {
-            const int sl = slots_h[sq];
-            if (sl >= 0) {
-              if (role == 0) eval_slot_part<0>(ectx_h, s_h, dofs_h, sl, xl_h, uofs_h, kvl, svl, pl_h, st_h);
-              if (role == 1 ? (p.pair_dbg & 1) == 0 : (p.pair_dbg & 1) == 1) eval_slot_part<1>(ectx_h, s_h, dofs_h, sl, xl_h, uofs_h, kvl, svl, pl_h, st_h);
-            }
+          if (!(half ? d1 : d0)) {
+            if (role == 0) eval_cached<0>(smeta, gmin_h, xl_h, kvl, svl, pl_h, st_h);
+            if (role == 1 ? (p.pair_dbg & 1) == 0 : (p.pair_dbg & 1) == 1) eval_cached<1>(smeta, gmin_h, xl_h, kvl, svl, pl_h, st_h);
           }
           pair_sync();                                   // both halves of every stamp record are in LDS
           P_STAMP(4);   // device evaluation (one half of it)
           if (pair_broken) break;
           if (done_own) continue;
         } else {
-        if (lane < cm.nslots) { const int sl = slots[lane]; if (sl >= 0) eval_slot<false>(ectx, s, dofs, sl, xl, uofs, kvl, svl, pl, st); }
+        eval_cached<-1>(smeta, gmin_h, xl, kvl, svl, pl, st);
         lds_fence();
         P_STAMP(4);   // device evaluation
         }
