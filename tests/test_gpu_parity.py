@@ -779,3 +779,31 @@ def test_device_heavy_small_block_takes_the_sparse_path():
     sol = dc(c)
     assert sol.retcode == "Success"
     assert approx(sol["b"][0], 0.5, 1e-9) and approx(sol["m"][0], 0.25, 1e-9)
+
+
+def test_sweep_with_dc_warm_start_gives_the_same_answers():
+    """CircuitSweep(warm_start=True): every sample's DC starts from the first point's operating point instead of ten random
+    restarts — same results on the reference's 400-point divider sweep and on a small Monte-Carlo of the DFF transient."""
+    def two_resistor(R1=100.0, R2=100.0):
+        c = Circuit()
+        c.V("V", "vcc", 0, dc=1.0)
+        c.R("R1", "vcc", "mid", R1)
+        c.R("R2", "mid", 0, R2)
+        return c
+    sw = ProductSweep(R1=frange(100.0, 100.0, 2000.0), R2=frange(100.0, 100.0, 2000.0))
+    cold, warm = dc(CircuitSweep(two_resistor, sw), abstol=DEFTOL), dc(CircuitSweep(two_resistor, sw, warm_start=True), abstol=DEFTOL)
+    for a, b in zip(cold, warm):
+        assert b.retcode == "Success" and approx(a["V.I"][0], b["V.I"][0])
+    def mc(dv=0.0):
+        c = dff_array(1, observe="q0")
+        i = c.model_names.index("nfet_06v0")
+        c.models[i][B4.PARAM_INDEX["vth0"]] += dv
+        return c
+    from cedarsim_jl_amd import Sweep
+    dvs = [float(x) for x in np.linspace(-0.03, 0.03, 16)]
+    sv = np.array(DFF_CHECK_TIMES)
+    a = tran(CircuitSweep(mc, Sweep(dv=dvs)), (0.0, 7e-7), abstol=1e-5, reltol=1e-5, dc_abstol=1e-13, saveat=sv)
+    b = tran(CircuitSweep(mc, Sweep(dv=dvs), warm_start=True), (0.0, 7e-7), abstol=1e-5, reltol=1e-5, dc_abstol=1e-13, saveat=sv)
+    for x, y in zip(a, b):
+        assert y.retcode == "Success" and np.max(np.abs(np.array(x["q"]) - np.array(y["q"]))) < 5e-4
+        assert np.max(np.abs(np.array(y["q"]) - np.array(DFF_CHECK_Q))) < 1e-3
