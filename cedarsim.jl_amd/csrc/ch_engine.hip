@@ -1048,7 +1048,9 @@ struct ch_circuit {
   // Device-resident step controller: which circuits qualify (ch_persist.hpp header), and the launch.
   DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl;
   int n_cu = 0;
-  bool persist_eligible(std::string& why) {
+  // `own_steps`: the batch would run with per-sample step acceptance (no grid-wide wait anywhere in the kernel), so the workgroups
+  // need not be co-resident and any number of samples can be queued behind each other
+  bool persist_eligible(std::string& why, bool own_steps) {
     auto no = [&](const char* m) { why = m; return false; };
     if (path != 1) return no("the circuit takes the sparse path");
     if (A.n_comp < 1) return no("the circuit has no unknowns");
@@ -1061,10 +1063,13 @@ struct ch_circuit {
     for (const ClassMeta& m : h_cms) if (m.nslots > 64 || m.nc > lu_variant || m.n_work <= 0) return no("a block class does not fit the one-wave register path");
     if (n_cu == 0) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return no("hipGetDeviceProperties failed"); n_cu = prop.multiProcessorCount; }
     const long nblk = (long)A.n_comp * S;
-    if (nblk > (long)PW * n_cu) return no("more blocks than resident wavefronts (4 per CU)");
+    if (nblk > (long)PW * n_cu && !own_steps) return no("more blocks than resident wavefronts (4 per CU)");
     size_t npwl = 0; for (int i : needed_src) npwl += src[i].ts.size();
     if (npwl > 2048) return no("piecewise-linear tables above 2048 points");
     return true;
+  }
+  bool persist_own_steps(const ch_tran_opts& o) const {
+    return A.n_comp == 1 && S > 1 && o.n_saveat > 0 && std::getenv("CEDARHIP_LOCKSTEP") == nullptr;
   }
   size_t persist_wave_doubles() const {
     return lds_doubles_fixed + 16 * (size_t)A.max_nc + 10 + 48 + P_MAXSRC + A.known.size() + n_dev_src() + (size_t)max_mc * B4L_STRIDE + (lds_extra_bytes + 7) / 8 + 2;
@@ -1109,7 +1114,7 @@ struct ch_circuit {
     HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(bps, st));
     { std::vector<double> sv(o.saveat, o.saveat + std::max(0, o.n_saveat)); if (sv.empty()) sv.push_back(0.0); HIPCHK(d_psave.upload(sv, st)); }
     HIPCHK(d_ptimes.alloc((size_t)max_rows)); HIPCHK(d_prows.alloc((size_t)max_rows * row_d));
-    HIPCHK(d_wgrec.alloc((size_t)2 * n_wg * 16)); HIPCHK(d_grprec.alloc(2 * 8 * 16)); /* 16 granules per record, double-buffered by generation parity */ HIPCHK(d_pcnt.alloc(10 * 32)); HIPCHK(d_pctl.alloc(1));
+    HIPCHK(d_wgrec.alloc((size_t)2 * n_wg * 16)); HIPCHK(d_grprec.alloc(2 * 8 * 16)); /* 16 granules per record, double-buffered by generation parity */ HIPCHK(d_pcnt.alloc(10 * 32)); HIPCHK(d_pctl.alloc(2));   /* controller state in; [1]: exit state of a batch with per-sample steps */
     PersistArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.a = base;
     pa.a.mode = MODE_TRAN; pa.a.maxit = nmaxit; pa.a.abstol = o.abstol; pa.a.reltol = o.reltol; pa.a.newton_tol = 0.1; pa.a.active = nullptr; pa.a.gshunt = 0.0;
@@ -1121,7 +1126,8 @@ struct ch_circuit {
     pa.ctl = d_pctl.p; pa.wg_rec = d_wgrec.p; pa.grp_rec = d_grprec.p; pa.counters = d_pcnt.p;
     pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz
     // a batch of single-block samples on a common output grid: every sample its own step sequence (no lock-step, no grid reduction)
-    pa.indep = (A.n_comp == 1 && S > 1 && o.n_saveat > 0 && std::getenv("CEDARHIP_LOCKSTEP") == nullptr) ? 1 : 0;
+    pa.indep = persist_own_steps(o) ? 1 : 0;
+    const bool coop = !pa.indep || nblk <= PW * n_cu;   // without grid-wide waits the workgroups may queue behind each other
     pa.pair_dbg = std::getenv("CEDARHIP_PAIR_DBG") ? std::atoi(std::getenv("CEDARHIP_PAIR_DBG")) : 0;
     // initial controller state (same first step as the host stepper)
     TranCtl cs; std::memset(&cs, 0, sizeof(cs));
@@ -1142,12 +1148,14 @@ struct ch_circuit {
     int resume = 0, status = CH_OK;
     for (;;) {
       HIPCHK(hipMemcpyAsync(d_pctl.p, &cs, sizeof(cs), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(d_pctl.p + 1, &cs, sizeof(cs), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemsetAsync(d_pcnt.p, 0, 10 * 32 * sizeof(unsigned), st));
       HIPCHK(hipMemsetAsync(d_wgrec.p, 0, (size_t)2 * n_wg * 16 * sizeof(double), st)); HIPCHK(hipMemsetAsync(d_grprec.p, 0, 2 * 8 * 16 * sizeof(double), st));   // generation tags start at 0
       pa.resume = resume;
       void* kargs[] = {(void*)&pa};
       HIPCHK(hipEventRecord(ev0, st));
-      const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(n_wg), dim3(PW * 64), kargs, (unsigned)lds, st);
+      const hipError_t le = coop ? hipLaunchCooperativeKernel(fn, dim3(n_wg), dim3(PW * 64), kargs, (unsigned)lds, st)
+                                 : hipLaunchKernel(fn, dim3(n_wg), dim3(PW * 64), kargs, lds, st);
       if (le != hipSuccess) {
         (void)hipGetLastError();
         if (resume == 0) { set_err(std::string("cooperative launch refused: ") + hipGetErrorString(le)); return CH_OK; }   // fall back to the host stepper
@@ -1157,7 +1165,7 @@ struct ch_circuit {
       used = true;
       { const hipError_t se = hipStreamSynchronize(st); if (se != hipSuccess) { set_err(std::string("device-resident stepper: ") + hipGetErrorString(se)); return CH_ERR_DEVICE; } }
       { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); persist_ms += ms; persist_launches += 1; }
-      HIPCHK(hipMemcpy(&cs, d_pctl.p, sizeof(cs), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&cs, d_pctl.p + (pa.indep ? 1 : 0), sizeof(cs), hipMemcpyDeviceToHost));
       // rows of this launch
       const size_t nr = (size_t)cs.nsaved;
       const size_t base_t = htimes.size();
@@ -1245,7 +1253,7 @@ struct ch_circuit {
       if (want == CH_STEPPER_AUTO && ev) want = std::strcmp(ev, "host") == 0 ? CH_STEPPER_HOST : (std::strcmp(ev, "device") == 0 ? CH_STEPPER_DEVICE : CH_STEPPER_AUTO);
       if (want != CH_STEPPER_HOST) {
         std::string why;
-        if (persist_eligible(why)) {
+        if (persist_eligible(why, persist_own_steps(o))) {
           bool used = false;
           rc = tran_persistent(t0, t1, o, R, bps, kmax, dtmin, dtmax, max_steps, nmaxit, tstart, used);
           if (used) return rc;

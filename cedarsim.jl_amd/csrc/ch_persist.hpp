@@ -815,8 +815,9 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   }
   if (p.indep) {
     // every sample reports for itself: sums of iterations, the longest chain of attempts, the worst status
+    // (into the second record: workgroups queued behind this one still read their initial state from the first)
     if (live && lane == 0) {
-      TranCtl* cs = p.ctl;
+      TranCtl* cs = p.ctl + 1;
       typedef unsigned long long u64;
       atomicAdd((u64*)&cs->sum_iters, (u64)stl[ST_ITERS]); atomicAdd((u64*)&cs->sum_block_iters, (u64)stl[ST_BITERS]);
       atomicMax((u64*)&cs->naccept, (u64)stl[ST_ACC]); atomicMax((u64*)&cs->nreject, (u64)stl[ST_REJ]); atomicMax((u64*)&cs->nconvfail, (u64)stl[ST_FAIL]);

@@ -32,16 +32,23 @@ if only in ("all", "config4"):
     e = EngineCircuit(c)
     e.set_samples(S)
     e.set_params(slots, vals)
-    opts = tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14), saveat=np.array(DFF_CHECK_TIMES))
-    e.tran(0.0, 7e-7, opts)
-    t0 = time.perf_counter()
-    rc, t, v, xf, st = e.tran(0.0, 7e-7, opts)
-    el = time.perf_counter() - t0
-    ok = np.abs(v[0] - np.array(DFF_CHECK_Q)[:, None]) < 1e-3
-    out["config4_mc8192"] = {"rc": rc, "samples": S, "wall_seconds": el, "launches": st["n_kernel_launches"],
-                             "avg_launch_us": 1e6 * st["device_seconds"] / max(1, st["n_kernel_launches"]),
-                             "block_iterations": st["n_block_iters"], "block_iterations_per_second": st["n_block_iters"] / el,
-                             "samples_passing_reference_gate": int(ok.all(axis=0).sum())}
+    e1 = EngineCircuit(dff_array(1))
+    rc0, x_nom, _, _ = e1.dc(dc_opts(abstol=1e-14))
+    res = {}
+    # host: one launch per attempt, lock-step batch; device: per-sample step acceptance, 2048 queued workgroups of 4 samples;
+    # device_dc_from_nominal: the same with every sample's DC started from the nominal operating point (CircuitSweep(warm_start=True))
+    for label, stepper, dco in (("host", "host", dc_opts(abstol=1e-14)), ("device", "device", dc_opts(abstol=1e-14)),
+                                ("device_dc_from_nominal", "device", dc_opts(abstol=1e-14, x0=np.tile(x_nom[0], (S, 1))))):
+        opts = tran_opts(abstol=1e-4, reltol=1e-4, dc=dco, saveat=np.array(DFF_CHECK_TIMES), stepper=stepper)
+        e.tran(0.0, 7e-7, opts)
+        t0 = time.perf_counter()
+        rc, t, v, xf, st = e.tran(0.0, 7e-7, opts)
+        el = time.perf_counter() - t0
+        ok = np.abs(v[0] - np.array(DFF_CHECK_Q)[:, None]) < 1e-3
+        res[label] = {"rc": rc, "wall_seconds": el, "dc_seconds": st["dc_seconds"], "launches": st["n_kernel_launches"],
+                      "block_iterations": st["n_block_iters"], "block_iterations_per_second": st["n_block_iters"] / el,
+                      "samples_passing_reference_gate": int(ok.all(axis=0).sum())}
+    out["config4_mc8192"] = {"samples": S, **res}
 if only in ("all", "config4_share"):
     S = 1024
     c = dff_array(1)

@@ -104,6 +104,33 @@ def test_monte_carlo_batch_on_the_device_stepper(E):
     assert len({tuple(np.round(vd[0, :, s], 9)) for s in range(S)}) > S // 2   # the samples really differ
 
 
+def test_more_samples_than_resident_wavefronts_queue_on_the_device_stepper(E):
+    """Per-sample step acceptance has no grid-wide wait, so a batch larger than the 1024 co-resident wavefronts is launched as
+    an ordinary (queued) grid: 2500 RC samples with their own resistances against the closed form of each."""
+    c = Circuit()
+    c.V("v", "in", 0, dc=0.0, tran=PWL([0.0, 0.0, 1e-9, 1.0]))
+    c.R("r", "in", "o", 1e3)
+    c.C("c", "o", 0, 1e-9)
+    c.observe_node("o")
+    S = 2500
+    slot = c.slot("r", "r")
+    e = E(c)
+    e.set_samples(S)
+    rs = np.linspace(500.0, 3000.0, S)
+    e.set_params([slot], [rs])
+    sv = np.linspace(0.0, 1e-5, 101)
+    td, vd, _, std = run(e, (0.0, 1e-5), "device", abstol=1e-9, reltol=1e-7, saveat=sv)
+    assert std["stepper"] == 2 and vd.shape == (1, 101, S)
+    m = sv > 2e-8
+    for s_ in (0, 1, 1023, 1024, 1025, 2047, 2048, 2499):
+        tau = rs[s_] * 1e-9
+        # ramp of 1 ns, then a plateau: v = 1 - tau/1ns (exp(-(t-1ns)/tau) - exp(-t/tau))
+        ref = 1.0 - tau / 1e-9 * (np.exp(-(sv[m] - 1e-9) / tau) - np.exp(-sv[m] / tau))
+        assert np.max(np.abs(vd[0, m, s_] - ref)) < 2e-6, (s_, np.max(np.abs(vd[0, m, s_] - ref)))
+    th, vh, _, sth = run(e, (0.0, 1e-5), "host", abstol=1e-9, reltol=1e-7, saveat=sv)
+    assert np.max(np.abs(vh - vd)) < 1e-5
+
+
 def test_row_buffer_drain_and_resume(E):
     """Without saveat every accepted step is a row; when the device row buffer fills, the kernel stops with its controller state
     and history written back and the host relaunches it (resume): the result must not depend on where the cuts fall."""
