@@ -230,7 +230,9 @@ struct ch_circuit {
   DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ, d_dumpC, d_dumpG, d_dumpF0, d_temp, d_omega, d_xac, d_psd;
   DevBuf<int> d_noise_a, d_noise_b, d_noise_h, d_acfail;
   DevBuf<double> d_noise_pwr, d_noise_exp;
-  DevBuf<double> d_vapar;
+  DevBuf<double> d_vapar, d_vacache;
+  DevBuf<int> d_dvac, d_va_mod, d_va_pofs, d_va_cofs;   // constant blocks of the Verilog-A instances: offset per flattened device; setup work list
+  int n_va_inst = 0; size_t vac_total = 0; long vac_stride_ = 0;
   std::vector<double> va_par;   // parameter blocks of the Verilog-A instances
   int Stemp = 1, Sva = 1;
   double ac_scale = 0.0;        // eval_sources adds ac_scale*|ac| to every source value (AC right-hand side)  // (d_srcv unused: source values share d_kv)
@@ -356,6 +358,20 @@ struct ch_circuit {
       for (const KnownDef& kd : A.known) for (auto& tm : kd.terms) need[tm.first] = 1;
       needed_src.clear();
       for (size_t i = 0; i < src.size(); ++i) if (need[i]) needed_src.push_back((int)i); }
+    { // constant blocks (va_gen::setup) of the compiled Verilog-A instances
+      std::vector<int> dvac(A.edev.size(), 0), vmod, vpofs, vcofs;
+      vac_total = 0;
+      for (size_t i = 0; i < A.edev.size(); ++i) {
+        const EDev& e = A.edev[i];
+        if (e.kind != K_VA) continue;
+        const int mod = dev[e.hdev].ipar[0];
+        dvac[i] = (int)vac_total; vmod.push_back(mod); vpofs.push_back(dev[e.hdev].ipar[1]); vcofs.push_back((int)vac_total);
+        vac_total += (size_t)va_gen::N_CACHE[mod];
+      }
+      n_va_inst = (int)vmod.size();
+      if (vmod.empty()) { vmod.push_back(0); vpofs.push_back(0); vcofs.push_back(0); }
+      HIPCHK(d_dvac.upload(dvac, st)); HIPCHK(d_va_mod.upload(vmod, st)); HIPCHK(d_va_pofs.upload(vpofs, st)); HIPCHK(d_va_cofs.upload(vcofs, st));
+    }
     std::vector<unsigned char> dm(A.n_unk, 0);
     for (int u = 0; u < A.n_unk; ++u) dm[u] = (A.diff_mask[u] ? 1 : 0) | (A.unk_mna[u] >= n_nodes ? 2 : 0);
     std::vector<int> obs_unk, unk_obs(A.n_unk, -1);
@@ -453,6 +469,16 @@ struct ch_circuit {
       for (int s = 0; s < Sva; ++s) std::copy(va_par.begin(), va_par.end(), vp.begin() + (size_t)s * nvp);
       for (int i = 0; i < nslot; ++i) if (slot_set(i) && slot_kind[i] == CH_SLOT_VA_PAR) for (int s = 0; s < Sva; ++s) vp[(size_t)s * nvp + slot_a[i]] = slot_val[i][s];
       HIPCHK(d_vapar.upload(vp, st));
+      // the bias-independent part of every instance, once per parameter / temperature change
+      const int Svac = (Sva > 1 || Stemp > 1) ? S : 1;
+      HIPCHK(d_vacache.alloc(std::max<size_t>(1, vac_total * (size_t)Svac)));
+      if (n_va_inst > 0) {
+        const long nthr = (long)n_va_inst * Svac;
+        hipLaunchKernelGGL(va_setup_kernel, dim3((unsigned)((nthr + 63) / 64)), dim3(64), 0, st, n_va_inst, Svac, d_va_mod.p, d_va_pofs.p, d_va_cofs.p,
+                           d_vapar.p, Sva > 1 ? (long)nvp : 0L, d_temp.p, Stemp, d_vacache.p, Svac > 1 ? (long)vac_total : 0L);
+        HIPCHK(hipGetLastError());
+      }
+      vac_stride_ = Svac > 1 ? (long)vac_total : 0L;
     }
     // MOS classes: instances with identical (model, geometry, overriding slots) share a column
     const int nmos = (int)A.mos_hdev.size();
@@ -549,6 +575,7 @@ struct ch_circuit {
     a.blob = d_gl_ptr.p; a.dkind = d_dkind.p; a.dterm = d_dterm.p; a.dsrc = d_dsrc.p; a.dcls = d_dcls.p; a.dhdev = d_dhdev.p;
     a.dpar = d_dpar.p; a.dmult = d_dmult.p; a.mosp = d_mosp.p; a.mos_cols = cols; a.kv = d_kv.p; a.srcv = d_kv.p + (size_t)Ssrc * A.known.size(); a.dmask = d_dmask.p;
     a.active = nullptr; a.gmin_s = d_gmin.p; a.vapar = d_vapar.p; a.va_stride = Sva > 1 ? (long)std::max<size_t>(1, va_par.size()) : 0; a.temp_s = d_temp.p; a.Stemp = Stemp;
+    a.vacache = d_vacache.p; a.vac_stride = vac_stride_; a.dvac = d_dvac.p;
     a.n_comp = A.n_comp; a.S = S; a.Spar = Spar; a.Ssrc = Ssrc; a.Smos = Smos; a.Sgmin = Sgmin; a.nk = (int)A.known.size(); a.nsrc = n_dev_src();
     a.n_unk = A.n_unk; a.n_mos_cls = n_cls;
     a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = host_reduce ? h_out : d_out.p;

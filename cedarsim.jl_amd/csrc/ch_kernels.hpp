@@ -71,6 +71,8 @@ struct NewtonArgs {
   const double* dpar; const double* dmult;   // [n_hdev * Spar]
   const double* vapar; long va_stride;       // parameter blocks of the compiled Verilog-A instances [Sva][va_stride] (dsrc[d] = offset, dcls_local[d] = module; va_stride = 0 when shared by all samples)
   const double* temp_s; int Stemp;           // Celsius per sample ($temperature of Verilog-A modules)
+  const double* vacache; long vac_stride;    // per-instance constants of the Verilog-A instances (va_gen::setup), [Svac][vac_stride]; dvac[d] = offset
+  const int* dvac;
   const double* mosp; long mos_cols;         // packed BSIM4 table [mos_cols][B4I_COUNT]
   const double* kv; const double* srcv;      // known-node values [Ssrc][nk], source values [Ssrc][nsrc]
   const unsigned char* dmask;                // per unknown: bit0 differential, bit1 branch current
@@ -129,6 +131,7 @@ struct EvalCtx {
   double gmin;
   const double* vapar;
   double temp_k;
+  const double* vacache; const int* dvac;   // this sample's constant blocks of the compiled Verilog-A instances
 };
 
 // stamp record layouts: narrow [I(4)|Q(4)|G(4x4)|C(4x4)] = 40 doubles; wide (a compiled Verilog-A device is
@@ -205,7 +208,7 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
     for (int k = 0; k < NTERM; ++k) { const int t = tm[k]; vv[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
     const long pi = (long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0);
     const va::Env env{a.temp_k, a.gmin};
-    va_gen::stamp_dir(a.dcls_local[d], a.vapar + a.dsrc[d], vv, env, a.dmult[pi], slot & 7, (slot & 8) != 0, st_final);
+    va_gen::stamp_dir_c(a.dcls_local[d], a.vapar + a.dsrc[d], a.vacache + a.dvac[d], vv, env, a.dmult[pi], slot & 7, (slot & 8) != 0, st_final);
     return;
   }
   double tmp40[WIDE ? 40 : 1];
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
     const double rate_prev = (a.mode == MODE_TRAN && !a.reset_rate) ? a.rate[blk] : 1.0;
     double rate_new = -1.0, dn_prev = 0.0;  // wave 0 only
     const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar + (long)s * a.va_stride,
-                       WIDE ? a.temp_s[a.Stemp > 1 ? s : 0] + 273.15 : 300.15};
+                       WIDE ? a.temp_s[a.Stemp > 1 ? s : 0] + 273.15 : 300.15, a.vacache + (long)s * a.vac_stride, a.dvac};
     for (int it = 0; it <= maxit; ++it) {
       // (1) device evaluation → staging (all waves)
       for (int q = tid; q < cm.nslots; q += nthr) { const int sl = slots[q]; if (sl >= 0) eval_slot<WIDE>(ectx, s, dofs, sl, xl, uofs, kvl, svl, pl, st); }
@@ -1154,6 +1157,17 @@ __global__ void noise_table_kernel(const NoiseTabArgs a) {
 }
 
 // one compiled Verilog-A module at given node voltages (ch_va_eval: stamp-level parity entry point)
+// Per-instance constants of the compiled Verilog-A devices: one thread per (instance, sample).  Runs whenever parameters or
+// the temperature change (ch_circuit::finalize_params), never inside the Newton loop.
+__global__ void va_setup_kernel(int n_va, int Svac, const int* vmod, const int* vpofs, const int* vcofs, const double* vapar, long va_stride,
+                                const double* temp_s, int Stemp, double* cache, long vac_stride) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n_va * Svac) return;
+  const int d = (int)(i % n_va), s = (int)(i / n_va);
+  const va::Env env{temp_s[Stemp > 1 ? s : 0] + 273.15, 0.0};   // $simparam("gmin") is not a setup-time quantity (gmin stepping)
+  va_gen::setup(vmod[d], vapar + (long)s * va_stride + vpofs[d], env, cache + (long)s * vac_stride + vcofs[d]);
+}
+
 __global__ void va_eval_kernel(int mod, const double* P, const double* v, double temp_k, double gmin, double* st) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double vv[NTERM], out[144];

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   lds_fence();
   __syncthreads();
 
-  const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar, 300.15};
+  const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar, 300.15, nullptr, nullptr};
   // this lane's device for the whole transient (block `half` of the pair when PAIR, the wave's own block otherwise)
   const double gmin_h = a.gmin_s[a.Sgmin > 1 ? (PAIR ? s_h : s) : 0];
   SlotMeta smeta;

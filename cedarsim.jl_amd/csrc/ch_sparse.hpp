@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
       else vv[k] = kvl[-t - 1];
     }
     const va::Env env{a.temp_s[a.Stemp > 1 ? sm : 0] + 273.15, gmin};
-    va_gen::stamp(a.dcls_local[dev], a.vapar + (long)sm * a.va_stride + a.dsrc[dev], vv, env, m, st_final);
+    va_gen::stamp_c(a.dcls_local[dev], a.vapar + (long)sm * a.va_stride + a.dsrc[dev], a.vacache + (long)sm * a.vac_stride + a.dvac[dev], vv, env, m, st_final);
     return;
   }
   double tmp40[40];

@@ -144,6 +144,14 @@ class ModuleGen:
         """ctx: dict(vars={name: type}, S=scalar type name for 'dual', infunc=bool)"""
         k = e[0]
         S = ctx["S"]
+        if ctx.get("setup_out") is not None and self._worth_hoisting(e) and self.is_static(e, ctx["cache"], ctx["vars"]):
+            # a bias-independent sub-expression of a bias-dependent statement: evaluated by setup() at this point of the
+            # (static) control flow, loaded here
+            c, t = self.expr(e, ctx["setup_ctx"])
+            slot = self._new_slot()
+            ctx["setup_out"].append((slot, "%sC[@%d@] = (double)(%s);" % (ctx.get("pad", "  "), slot, c)))
+            self.used_slots.add(slot)
+            return ("(int)C[@%d@]" % slot, "int") if t == "int" else ("C[@%d@]" % slot, "real")
         if k == "num":
             if e[2]:
                 return str(e[1]), "int"
@@ -156,6 +164,9 @@ class ModuleGen:
         if k == "id":
             name = e[1]
             if name in ctx["vars"]:
+                cache = ctx.get("cache")
+                if cache is not None and cache.get(name) is not None:
+                    return self._load(name, cache[name], ctx["vars"][name])
                 return "v_" + name, ctx["vars"][name]
             if name in self.param_ix:
                 ty = self.param_ty[name]
@@ -458,9 +469,13 @@ class ModuleGen:
             out = ["%s{" % pad]
             if st[2]:
                 ctx = dict(ctx, vars=dict(ctx["vars"]))
+                if ctx.get("cache") is not None:
+                    ctx["cache"] = dict(ctx["cache"])
                 for nm, ty in st[2].items():
                     t = "int" if ty == "integer" else ("dual" if (ctx.get("infunc") or nm in self.dual) else "real")
                     ctx["vars"][nm] = t
+                    if ctx.get("cache") is not None:
+                        ctx["cache"][nm] = None
                     out.append("%s  %s v_%s%s;" % (pad, {"int": "int", "real": "double", "dual": S}[t], nm, self._decl_suffix(nm)))
             for s in st[3]:
                 out += self.stmt(s, ctx, ind + 1)
@@ -549,6 +564,261 @@ class ModuleGen:
                         mask |= 1 << self.node_ix[nd]
         return mask
 
+    # ---- setup / eval split (binding-time analysis) ----
+    # The reference constant-folds everything that depends only on the instance parameters when it compiles the circuit
+    # (`DefaultSim` parameters are compile-time constants, src/circuitodesystem.jl:57-62).  Here the analog block is split
+    # into `setup(P, env, C)`, which runs the bias-independent statements once per instance and parameter change and stores
+    # what the rest needs into the per-instance constant block C, and `eval(P, C, V, ...)`, the bias-dependent remainder.
+    # The analysis is flow-sensitive (BSIM code reuses its temporaries T0..T9 for both kinds of value): walking the statements
+    # in order, `state[var]` is the slot of C that holds the variable's current value, or None once it depends on a node
+    # voltage (by data, or by being assigned under a bias-dependent condition).  Conditions that are themselves
+    # bias-independent are kept as control flow on both sides (their truth value is a slot); where the branches disagree
+    # about a variable, a merge slot (both static) or a materialisation `v = C[slot]` at the end of the static branch is made.
+    def _new_slot(self):
+        self.n_slots += 1
+        return self.n_slots - 1
+
+    def _load(self, name, slot, ty):
+        if slot < 0:   # never assigned so far: Verilog-A variables start at zero
+            return ("0", "int") if ty == "int" else ("0.0", "real")
+        self.used_slots.add(slot)
+        return ("(int)C[@%d@]" % slot, "int") if ty == "int" else ("C[@%d@]" % slot, "real")
+
+    def _materialise(self, name, slot, ty, pad):
+        c, t = self._load(name, slot, ty)
+        return "%sv_%s = %s;" % (pad, name, self.cast(c, t, ty, "R"))
+
+    @staticmethod
+    def _worth_hoisting(e):
+        if e[0] == "bin":
+            return e[1] in ("/", "**")
+        return e[0] == "call" and not e[1].startswith("$") and e[1] not in POTENTIAL_ACCESS and e[1] not in FLOW_ACCESS and e[1] not in ("ddx", "ddt", "white_noise", "flicker_noise")
+
+    def is_static(self, e, state, vars_):
+        k = e[0]
+        if k in ("num", "str"):
+            return True
+        if k == "id":
+            if e[1] in vars_:
+                return state.get(e[1]) is not None
+            return e[1] in self.param_ix
+        if k == "index":
+            return False
+        if k == "un":
+            return self.is_static(e[2], state, vars_)
+        if k == "bin":
+            return self.is_static(e[2], state, vars_) and self.is_static(e[3], state, vars_)
+        if k == "tern":
+            return all(self.is_static(x, state, vars_) for x in e[1:4])
+        if k == "call":
+            name = e[1]
+            if name in POTENTIAL_ACCESS or name in FLOW_ACCESS or name in ("ddx", "ddt", "$simparam", "$limit", "$abstime", "$realtime"):
+                return False     # $simparam("gmin") changes between launches of one solve (gmin stepping)
+            if name in ("$param_given", "$given", "$mfactor", "$port_connected", "white_noise", "flicker_noise"):
+                return True
+            if name in self.m.functions and any(kind != "input" for _, kind in self.m.functions[name].args):
+                return False
+            return all(self.is_static(a, state, vars_) for a in e[2] if a[0] != "str")
+        return False
+
+    def _assigned(self, st, out=None):
+        """names that a statement subtree may assign (output arguments of analog functions included)"""
+        out = set() if out is None else out
+        for n in _walk(st):
+            if not n or not isinstance(n[0], str):
+                continue
+            if n[0] in ("assign", "assign_idx"):
+                out.add(n[1])
+            elif n[0] == "call" and n[1] in self.m.functions:
+                for (nm, kind), a in zip(self.m.functions[n[1]].args, n[2]):
+                    if kind != "input" and a[0] == "id":
+                        out.add(a[1])
+        return out
+
+    def _split(self, st, state, dyn, sctx, ectx, ind):
+        """-> (setup lines, eval lines); setup lines that only store a slot are (slot, text) pairs, dropped later if unused"""
+        if st is None:
+            return [], []
+        k = st[0]
+        pad = "  " * ind
+        S, E = [], []
+
+        def ectx_here(hoist=True):
+            return dict(ectx, cache=state, setup_out=(S if hoist else None), setup_ctx=sctx, pad=pad)
+
+        def make_dynamic(names):
+            for nm in sorted(names):
+                if state.get(nm) is not None:
+                    if nm in ectx["vars"]:
+                        E.append(self._materialise(nm, state[nm], ectx["vars"][nm], pad))
+                    state[nm] = None
+
+        if k == "assign":
+            name = st[1]
+            if name not in ectx["vars"]:
+                raise VAError("assignment to undeclared variable '%s' in module %s" % (name, self.m.name))
+            outs = self._assigned(st[2])
+            if name in state and not dyn and not outs and self.is_static(st[2], state, ectx["vars"]):
+                c, t = self.expr(st[2], sctx)
+                S.append("%sv_%s = %s;" % (pad, name, self.cast(c, t, sctx["vars"][name], "double")))
+                slot = self._new_slot()
+                S.append((slot, "%sC[@%d@] = (double)v_%s;" % (pad, slot, name)))
+                state[name] = slot
+            else:
+                c, t = self.expr(st[2], ectx_here())
+                E.append("%sv_%s = %s;" % (pad, name, self.cast(c, t, ectx["vars"][name], "R")))
+                for nm in outs | {name}:
+                    if nm in state:
+                        state[nm] = None
+            return S, E
+        if k in ("assign_idx", "contrib"):
+            outs = self._assigned(st)
+            E += self.stmt(st, ectx_here(), ind)
+            for nm in outs:
+                if nm in state:
+                    state[nm] = None
+            return S, E
+        if k == "case":
+            sel, default, chain = st[1], None, []
+            for conds, body in st[2]:
+                if conds is None:
+                    default = body
+                    continue
+                test = None
+                for cd in conds:
+                    t1 = ("bin", "==", sel, cd)
+                    test = t1 if test is None else ("bin", "||", test, t1)
+                chain.append((test, body))
+            node = default
+            for test, body in reversed(chain):
+                node = ("if", test, body, node)
+            return self._split(node, state, dyn, sctx, ectx, ind)
+        if k == "if":
+            cond = st[1]
+            if not dyn and not self._assigned(cond) and self.is_static(cond, state, ectx["vars"]):
+                cs, _ = self.expr(cond, sctx)
+                kc = self._new_slot()
+                S.append((kc, "%sC[@%d@] = va::truth(%s) ? 1.0 : 0.0;" % (pad, kc, cs)))
+                stA, stB = dict(state), dict(state)
+                SA, EA = self._split(st[2], stA, False, sctx, ectx, ind + 1)
+                SB, EB = self._split(st[3], stB, False, sctx, ectx, ind + 1)
+                post = []
+                for nm in list(state):
+                    a, b = stA.get(nm), stB.get(nm)
+                    if a == b:
+                        state[nm] = a
+                    elif a is not None and b is not None:
+                        km = self._new_slot()
+                        post.append((km, "%sC[@%d@] = (double)v_%s;" % (pad, km, nm)))
+                        state[nm] = km
+                    else:
+                        (EA if a is not None else EB).append(self._materialise(nm, a if a is not None else b, ectx["vars"][nm], pad + "  "))
+                        state[nm] = None
+                S += ["%sif (va::truth(%s)) {" % (pad, cs)] + SA + ["%s} else {" % pad] + SB + ["%s}" % pad] + post
+                if EA or EB:
+                    self.used_slots.add(kc)
+                    E += ["%sif (C[@%d@] != 0.0) {" % (pad, kc)] + EA + (["%s} else {" % pad] + EB if EB else []) + ["%s}" % pad]
+                return S, E
+            make_dynamic(n for n in self._assigned(st) if n in state)
+            c, _ = self.expr(cond, ectx_here())
+            SA, EA = self._split(st[2], state, True, sctx, ectx, ind + 1)
+            SB, EB = self._split(st[3], state, True, sctx, ectx, ind + 1)
+            S += SA + SB
+            E += ["%sif (va::truth(%s)) {" % (pad, c)] + EA + (["%s} else {" % pad] + EB if EB else []) + ["%s}" % pad]
+            return S, E
+        if k == "block":
+            S.append("%s{" % pad)
+            E.append("%s{" % pad)
+            saved = {}
+            if st[2]:
+                sctx = dict(sctx, vars=dict(sctx["vars"]))
+                ectx = dict(ectx, vars=dict(ectx["vars"]))
+                for nm, ty in st[2].items():
+                    t = "int" if ty == "integer" else ("dual" if nm in self.dual else "real")
+                    ectx["vars"][nm] = t
+                    sctx["vars"][nm] = "int" if t == "int" else "real"
+                    E.append("%s  %s v_%s%s;" % (pad, {"int": "int", "real": "double", "dual": "R"}[t], nm, self._decl_suffix(nm)))
+                    S.append("%s  %s v_%s%s;" % (pad, "int" if t == "int" else "double", nm, self._decl_suffix(nm)))
+                    saved[nm] = state.get(nm, "absent")
+                    if nm in self.m.arrays:
+                        state.pop(nm, None)
+                    else:
+                        state[nm] = -1
+            n_body = 0
+            for s1 in st[3]:
+                s_, e_ = self._split(s1, state, dyn, sctx, ectx, ind + 1)
+                S += s_
+                E += e_
+                n_body += len(e_)
+            if n_body == 0:
+                E = ["#"]     # marker: nothing bias-dependent in this block (dropped below)
+            for nm, old in saved.items():
+                if old == "absent":
+                    state.pop(nm, None)
+                else:
+                    state[nm] = old
+            S.append("%s}" % pad)
+            if E == ["#"]:
+                E = []
+            else:
+                E.append("%s}" % pad)
+            return S, E
+        if k in ("for", "while", "repeat"):
+            make_dynamic(n for n in self._assigned(st) if n in state)
+            E += self.stmt(st, ectx_here(hoist=False), ind)
+            return S, E
+        if k == "event":
+            return self._split(st[1], state, dyn, sctx, ectx, ind)
+        if k in ("task", "null"):
+            return S, E
+        raise VAError("cannot generate statement %r" % (st,))
+
+    def generate_split(self, param_decls, vars_):
+        """lines of `setup` and of the cached `eval`; sets self.n_cache"""
+        import re
+        m = self.m
+        self.n_slots, self.used_slots = 0, set()
+        state = {nm: -1 for nm, t in vars_.items() if nm not in m.arrays}
+        sctx = {"vars": {k: ("real" if t == "dual" else t) for k, t in vars_.items()}, "S": "double", "noise": True}
+        ectx = {"vars": dict(vars_), "S": "R"}
+        S, E = [], []
+        for st in m.analog:
+            s_, e_ = self._split(st, state, False, sctx, ectx, 1)
+            S += s_
+            E += e_
+        order = sorted(self.used_slots)
+        final = {k: i for i, k in enumerate(order)}
+        self.n_cache = len(order)
+
+        def finish(lines):
+            out = []
+            for ln in lines:
+                if isinstance(ln, tuple):
+                    if ln[0] not in final:
+                        continue
+                    ln = ln[1]
+                out.append(re.sub(r"@(\d+)@", lambda mo: str(final[int(mo.group(1))]), ln))
+            return out
+        S, E = finish(S), finish(E)
+
+        def var_decls(scalar):
+            return ["  %s v_%s%s;" % ({"int": "int", "real": "double", "dual": scalar}[t], nm, self._decl_suffix(nm)) for nm, t in vars_.items()]
+        out = ["VA_HD_NOINLINE void setup(const double* P, const va::Env& env, double* C) {"]
+        out += param_decls + var_decls("double") + ["  (void)env; (void)P; (void)C;"] + S + ["}"]
+        out.append("template <class R> VA_HD_NOINLINE void eval(const double* P, const double* C, const R* V, const va::Env& env, R* I, R* Q) {")
+        out += param_decls + var_decls("R")
+        out.append("  (void)env; (void)V; (void)P; (void)C;")
+        for k in range(len(m.vbranches)):
+            out.append("  int bs%d_ = 0; R bv%d_ = R(0.0), bq%d_ = R(0.0);" % (k, k, k))
+        out += E
+        for k, key in enumerate(m.vbranches):
+            kb, a = self.node_ix[m.branch_node(key)], self.node_ix[key[0]]
+            vab = "V[%d]" % a if len(key) == 1 else "(V[%d] - V[%d])" % (a, self.node_ix[key[1]])
+            out.append("  I[%d] += V[%d];%s" % (a, kb, (" I[%d] -= V[%d];" % (self.node_ix[key[1]], kb)) if len(key) > 1 else ""))
+            out.append("  I[%d] += (bs%d_ == 1 ? %s : V[%d]) - bv%d_; Q[%d] -= bq%d_;" % (kb, k, vab, kb, k, kb, k))
+        out.append("}")
+        return out
+
     # ---- top level ----
     def function(self, f):
         targs = []
@@ -577,7 +847,6 @@ class ModuleGen:
         out.append("namespace m_%s {" % m.name)
         for f in m.functions.values():
             out += self.function(f)
-        out.append("template <class R> VA_HD_NOINLINE void eval(const double* P, const R* V, const va::Env& env, R* I, R* Q) {")
         np_ = len(m.params)
         used = set()
         for n in _walk([m.analog]):
@@ -601,19 +870,8 @@ class ModuleGen:
 
         def var_decls(scalar):
             return ["  %s v_%s%s;" % ({"int": "int", "real": "double", "dual": scalar}[t], nm, self._decl_suffix(nm)) for nm, t in vars_.items()]
-        out += param_decls + var_decls("R")
-        out.append("  (void)env; (void)V; (void)P;")
-        for k in range(len(m.vbranches)):   # voltage / switch branches: state (CURRENT at the start), value, charge
-            out.append("  int bs%d_ = 0; R bv%d_ = R(0.0), bq%d_ = R(0.0);" % (k, k, k))
-        ctx = {"vars": vars_, "S": "R"}
-        for st in m.analog:
-            out += self.stmt(st, ctx, 1)
-        for k, key in enumerate(m.vbranches):   # KCL rows get ±x_br; branch row: x_br − value (CURRENT) or V(a,b) − value (VOLTAGE)
-            kb, a = self.node_ix[m.branch_node(key)], self.node_ix[key[0]]
-            vab = "V[%d]" % a if len(key) == 1 else "(V[%d] - V[%d])" % (a, self.node_ix[key[1]])
-            out.append("  I[%d] += V[%d];%s" % (a, kb, (" I[%d] -= V[%d];" % (self.node_ix[key[1]], kb)) if len(key) > 1 else ""))
-            out.append("  I[%d] += (bs%d_ == 1 ? %s : V[%d]) - bv%d_; Q[%d] -= bq%d_;" % (kb, k, vab, kb, k, kb, k))
-        out.append("}")
+        # setup(P, env, C): the bias-independent statements; eval(P, C, V, ...): the rest (see _split)
+        out += self.generate_split(param_decls, vars_)
         # noise pass: same statements over plain doubles, contributions replaced by noise records
         self.has_noise = any(n and n[0] == "call" and n[1] in ("white_noise", "flicker_noise") for n in _walk(m.analog))
         if self.has_noise:
@@ -686,7 +944,17 @@ def generate_header(modules, source_tag=""):
     out.append("    for (int j = 0; j < NT; ++j) { st[16 + k * 8 + j] = m * va::val(I[k].d[j]); st[80 + k * 8 + j] = m * va::val(Q[k].d[j]); }")
     out.append("  }")
     out.append("}")
-    out.append("VA_HD_NOINLINE void stamp(int mod, const double* P, const double* v, const va::Env& env, double m, double* st) {")
+    out.append("static const int N_CACHE[] = {%s};" % (", ".join(str(g.n_cache) for g in gens) or "0"))
+    out.append("constexpr int MAX_CACHE = %d;" % max([1] + [g.n_cache for g in gens]))
+    out.append("// Per-instance constants of module `mod`: C[0 .. N_CACHE[mod]) from the parameter block and the temperature")
+    out.append("VA_HD_NOINLINE void setup(int mod, const double* P, const va::Env& env, double* C) {")
+    out.append("  switch (mod) {")
+    for i, g in enumerate(gens):
+        out.append("    case %d: m_%s::setup(P, env, C); break;" % (i, g.m.name))
+    out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
+    out.append("VA_HD_NOINLINE void stamp_c(int mod, const double* P, const double* C, const double* v, const va::Env& env, double m, double* st) {")
     out.append("  switch (mod) {")
     for i, g in enumerate(gens):
         mo = g.m
@@ -698,16 +966,22 @@ def generate_header(modules, source_tag=""):
         for k, node in enumerate(mo.nodes):
             dk = g.ddx_nodes.index(node) if node in g.ddx_nodes else -1
             out.append("      V[%d] = va::seed(v[%d], %d, %d, (R*)nullptr);" % (k, k, k, dk))
-        out.append("      m_%s::eval<R>(P, V, env, I, Q);" % mo.name)
+        out.append("      m_%s::eval<R>(P, C, V, env, I, Q);" % mo.name)
         out.append("      scatter<%d, R>(I, Q, m, st);" % nt)
         out.append("    } break;")
     out.append("    default: break;")
     out.append("  }")
     out.append("}")
+    out.append("// the same without a stored constant block (host-side callers, one-off evaluations): setup into a local block first")
+    out.append("VA_HD_NOINLINE void stamp(int mod, const double* P, const double* v, const va::Env& env, double m, double* st) {")
+    out.append("  double C[MAX_CACHE];")
+    out.append("  setup(mod, P, env, C);")
+    out.append("  stamp_c(mod, P, C, v, env, m, st);")
+    out.append("}")
     out.append("")
     out.append("// Direction-parallel evaluation: one lane per (device, node j) computes the values and the j-th column of the")
     out.append("// Jacobians with one-directional duals (VD<1,·>); the lane flagged `first` also writes I and Q.")
-    out.append("VA_HD_NOINLINE void stamp_dir(int mod, const double* P, const double* v, const va::Env& env, double m, int dir, bool first, double* st) {")
+    out.append("VA_HD_NOINLINE void stamp_dir_c(int mod, const double* P, const double* C, const double* v, const va::Env& env, double m, int dir, bool first, double* st) {")
     out.append("  switch (mod) {")
     for i, g in enumerate(gens):
         mo = g.m
@@ -719,7 +993,7 @@ def generate_header(modules, source_tag=""):
         for k, node in enumerate(mo.nodes):
             dk = g.ddx_nodes.index(node) if node in g.ddx_nodes else -1
             out.append("      V[%d] = va::seed1(v[%d], dir == %d, %d, (R*)nullptr);" % (k, k, k, dk))
-        out.append("      m_%s::eval<R>(P, V, env, I, Q);" % mo.name)
+        out.append("      m_%s::eval<R>(P, C, V, env, I, Q);" % mo.name)
         out.append("      for (int k = 0; k < %d; ++k) {" % nt)
         out.append("        if (first) { st[k] = m * va::val(I[k]); st[8 + k] = m * va::val(Q[k]); }")
         out.append("        st[16 + k * 8 + dir] = m * va::val(I[k].d[0]); st[80 + k * 8 + dir] = m * va::val(Q[k].d[0]);")

@@ -394,6 +394,107 @@ def test_generated_cpp_matches_interpreter_on_a_torture_module(tmp_path):
                 assert np.allclose(got, want, rtol=1e-11, atol=1e-11 * max(np.abs(want).max(), 1e-300)), (params, vb)
 
 
+SPLIT_TORTURE = """
+module cg_split(a, b, c);
+  inout a, b, c; electrical a, b, c;
+  parameter real G0 = 1e-3;
+  parameter real K = 0.7;
+  parameter integer MODE = 1;
+  parameter real TNOM = 27.0;
+  real T0, T1, T2, vab, vcb, gt, acc, late, carry, loopv, sel;
+  integer i, flag, cnt;
+
+  analog function real twice;
+    input x; output sq; real x, sq;
+    begin sq = x*x; twice = 2.0*x; end
+  endfunction
+
+  analog begin : main
+    real loc;
+    // temporaries that hold bias-independent and bias-dependent values in turn
+    T0 = exp(K) / (1.0 + K);             // static
+    gt = G0 * T0 * ($temperature / (TNOM + 273.15));
+    vab = V(a, b);
+    T0 = T0 * vab;                       // now dynamic
+    T1 = ln(2.0 + K);                    // static
+    I(a, b) <+ gt * (T0 + T1 * vab * vab);
+    T0 = sqrt(K + 1.0);                  // static again
+    // static condition, both branches static with different values -> merge slot
+    if (MODE > 0) begin T2 = T0 * 3.0; flag = 1; end else begin T2 = T0 / 3.0; flag = 2; end
+    // static condition, one branch bias-dependent -> the other is materialised
+    if (MODE == 2) carry = tanh(vab); else carry = 0.25 * T2;
+    // bias-dependent condition around bias-independent right-hand sides (incl. an expensive one that is hoisted)
+    vcb = V(c, b);
+    late = 0.5;
+    if (vcb > 0.1) begin late = pow(K, 1.5) + T1; loc = 2.0; end
+    else if (vcb < -0.1) late = -T2;
+    // case on a parameter
+    case (MODE)
+      0: sel = 0.0;
+      1, 3: sel = T1 * K;
+      default: begin sel = vab * K; end
+    endcase
+    // variables assigned in a loop are bias-dependent from there on; the loop reads static values
+    acc = T2;
+    for (i = 0; i < 3; i = i + 1) acc = acc + T1 * (i + 1) * vcb;
+    loopv = 0.0;
+    cnt = 0;
+    while (cnt < flag) begin loopv = loopv + T0; cnt = cnt + 1; end
+    // an analog function with an output argument on bias-independent input
+    T1 = twice(K, T2);
+    I(c, b) <+ 1e-3 * (carry + late + sel + acc + loopv * vcb + T1 * vab + T2 * vcb + loc * 0.0) + ddt(1e-12 * flag * T0 * vcb * vcb);
+    if (MODE == 3) I(a, c) <+ 1e-4 * V(a, c) * T0;
+  end
+endmodule
+"""
+
+
+def test_setup_eval_split_on_a_binding_time_torture_module(tmp_path):
+    """The setup/eval split (codegen.ModuleGen._split): temporaries reused for bias-independent and bias-dependent values,
+    merges after bias-independent conditions, materialisation where only one branch depends on the bias, a `case` on a
+    parameter, hoisted sub-expressions under bias-dependent control, loops, output arguments.  The constant block is built ONCE
+    per parameter set and reused for every bias (as the engine does); the result must equal the interpreter's."""
+    import ctypes as C
+    import subprocess
+    from cedarsim_jl_amd.va.codegen import generate_header
+    mods = parse_va(SPLIT_TORTURE)
+    hdr = generate_header(mods).replace('#include "../va_rt.hpp"', '#include "va_rt.hpp"')
+    assert "void setup(" in hdr
+    (tmp_path / "gen.hpp").write_text(hdr)
+    (tmp_path / "shim.cpp").write_text('#include "gen.hpp"\nextern "C" int n_cache() { return va_gen::N_CACHE[0]; }\n'
+                                       'extern "C" void setup(const double* P, double T, double gmin, double* Cc) { const va::Env env{T, gmin}; va_gen::setup(0, P, env, Cc); }\n'
+                                       'extern "C" void stamp_c(const double* P, const double* Cc, const double* v, double T, double gmin, double* st) {\n'
+                                       '  for (int k = 0; k < 144; ++k) st[k] = 0.0; const va::Env env{T, gmin}; va_gen::stamp_c(0, P, Cc, v, env, 1.0, st); }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libgen.so")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(root, "cedarsim.jl_amd", "csrc"), "-I", str(tmp_path),
+                        str(tmp_path / "shim.cpp"), "-o", so], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    L = C.CDLL(so)
+    pd = C.POINTER(C.c_double)
+    L.setup.argtypes = [pd, C.c_double, C.c_double, pd]
+    L.stamp_c.argtypes = [pd, pd, pd, C.c_double, C.c_double, pd]
+    nc = L.n_cache()
+    assert 4 <= nc <= 40, nc
+    mod = mods[0]
+    rng = np.random.default_rng(11)
+    for params in ({}, {"MODE": 0}, {"MODE": 2, "K": 0.3}, {"MODE": 3, "G0": 2e-3}, {"MODE": -1, "K": 1.4}):
+        it = Interp(mod, params, temperature_c=320.0 - 273.15)
+        P = np.array([float(it.params[p[0]]) for p in mod.params] + [1.0 if p[0] in it.given else 0.0 for p in mod.params])
+        Cc = np.full(max(1, nc), np.nan)
+        L.setup(P.ctypes.data_as(pd), 320.0, 1e-12, Cc.ctypes.data_as(pd))
+        for _ in range(6):
+            vb = {n: float(rng.uniform(-0.6, 0.9)) for n in mod.nodes}
+            I, Q, G, Cm = it.evaluate(vb)
+            v = np.zeros(8)
+            v[:3] = [vb[n] for n in mod.nodes]
+            st = np.zeros(144)
+            L.stamp_c(P.ctypes.data_as(pd), Cc.ctypes.data_as(pd), v.ctypes.data_as(pd), 320.0, 1e-12, st.ctypes.data_as(pd))
+            for got, want in ((st[:3], I), (st[8:11], Q), (st[16:80].reshape(8, 8)[:3, :3], G), (st[80:144].reshape(8, 8)[:3, :3], Cm)):
+                want = np.array(want, float)
+                assert np.allclose(got, want, rtol=1e-11, atol=1e-11 * max(np.abs(want).max(), 1e-300)), (params, vb, got, want)
+
+
 def test_switch_branch_state_semantics():
     """A branch that receives a voltage contribution on one path and a current contribution on the other: the branch state
     follows the last contribution executed (src/vasim.jl:128-180, 810-822)."""
