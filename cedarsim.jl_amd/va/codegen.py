@@ -197,7 +197,7 @@ class ModuleGen:
                 return "(%s %s %s)" % (a, op, b), self.promote(ta, tb)
             if op == "/":   # always real division (the reference maps `/` to Julia's `/`, src/vasim.jl:221-232)
                 t = self.promote(self.promote(ta, tb), "real")
-                return "(%s / %s)" % (self.cast(a, ta, t, S) if ta == "int" else a, self.cast(b, tb, t, S) if tb == "int" else b), t
+                return "va::v_div(%s, %s)" % (self.cast(a, ta, "real", S) if ta == "int" else a, self.cast(b, tb, "real", S) if tb == "int" else b), t
             if op == "**":
                 t = self.promote(self.promote(ta, tb), "real")
                 if ta == "dual" and tb != "dual":
@@ -803,9 +803,10 @@ class ModuleGen:
 
         def var_decls(scalar):
             return ["  %s v_%s%s;" % ({"int": "int", "real": "double", "dual": scalar}[t], nm, self._decl_suffix(nm)) for nm, t in vars_.items()]
-        out = ["VA_HD_NOINLINE void setup(const double* P, const va::Env& env, double* C) {"]
+        out = ["VA_HD_NOINLINE void setup(const double* P, const va::Env& env, double* C) {", "  VA_KEEP_RETURN_ADDRESS;"]
         out += param_decls + var_decls("double") + ["  (void)env; (void)P; (void)C;"] + S + ["}"]
         out.append("template <class R> VA_HD_NOINLINE void eval(const double* P, const double* C, const R* V, const va::Env& env, R* I, R* Q) {")
+        out.append("  VA_KEEP_RETURN_ADDRESS;")
         out += param_decls + var_decls("R")
         out.append("  (void)env; (void)V; (void)P; (void)C;")
         for k in range(len(m.vbranches)):
@@ -876,6 +877,7 @@ class ModuleGen:
         self.has_noise = any(n and n[0] == "call" and n[1] in ("white_noise", "flicker_noise") for n in _walk(m.analog))
         if self.has_noise:
             out.append("VA_HD_NOINLINE int noise(const double* P, const double* V, const va::Env& env, va::NoiseRec* out) {")
+            out.append("  VA_KEEP_RETURN_ADDRESS;")
             out.append("  int n_ = 0;")
             out += param_decls + var_decls("double")
             out.append("  (void)env; (void)V; (void)P;")
@@ -893,6 +895,7 @@ class ModuleGen:
         self.op_names = [nm for nm in m.var_desc if vars_.get(nm) in ("real", "dual", "int")]
         if self.op_names:
             out.append("VA_HD_NOINLINE void opvars(const double* P, const double* V, const va::Env& env, double* op) {")
+            out.append("  VA_KEEP_RETURN_ADDRESS;")
             out += param_decls + var_decls("double")
             out.append("  (void)env; (void)V; (void)P;")
             octx = {"vars": {k: ("real" if t == "dual" else t) for k, t in vars_.items()}, "S": "double", "noise": True, "opvars": True}
