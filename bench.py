@@ -221,7 +221,8 @@ def main():
                 pj = json.load(open(os.path.join(ROOT, "profiles", cand)))
             except Exception:  # noqa: BLE001
                 continue
-            if pj.get("lib_sha256") == lib_hash and pj.get("tiles", N_TILES) == args.tiles:
+            if pj.get("lib_sha256") == lib_hash and pj.get("tiles", N_TILES) == args.tiles and "bench.py" in pj.get("workload", "bench.py") \
+                    and pj.get("kernel", "") in ("tran_persistent_kernel", "newton_block_kernel"):
                 traffic = pj.get("hbm_bytes_per_launch")
                 flops = pj.get("fp64_flop_per_launch")
                 pmc_note = "profiles/%s (same library build, sha256 %s...)" % (cand, lib_hash[:12])

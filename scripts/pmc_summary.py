@@ -6,12 +6,15 @@ import os
 import sys
 
 out, tag = sys.argv[1], sys.argv[2]
-# the dominant kernel of the bench: the persistent transient kernel when the device-resident stepper ran, else the per-attempt kernel
-KERNEL = "tran_persistent_kernel"
-for f in glob.glob(os.path.join(out, tag + "_pmc_*", "**", "*counter_collection.csv"), recursive=True):
-    if "tran_persistent_kernel" not in open(f).read():
-        KERNEL = "newton_block_kernel"
-    break
+WORKLOAD = sys.argv[3] if len(sys.argv) > 3 else "bench.py --steps 1 --warmup 0 (1024-DFF array transient); per-launch averages"
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "auto"
+if KERNEL == "auto":
+    # the dominant kernel of the bench: the persistent transient kernel when the device-resident stepper ran, else the per-attempt kernel
+    KERNEL = "tran_persistent_kernel"
+    for f in glob.glob(os.path.join(out, tag + "_pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        if "tran_persistent_kernel" not in open(f).read():
+            KERNEL = "newton_block_kernel"
+        break
 
 
 def counters(dirname):
@@ -30,8 +33,8 @@ import hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cedarsim_jl_amd import engine as _eng  # noqa: E402
-res = {"kernel": KERNEL, "workload": "bench.py --steps 1 --warmup 0 (1024-DFF array transient); per-launch averages",
-       "tiles": 1024, "lib_sha256": hashlib.sha256(open(_eng.LIB_PATH, "rb").read()).hexdigest(), "ch_version": _eng.load_library().ch_version().decode(),
+res = {"kernel": KERNEL, "workload": WORKLOAD,
+       "lib_sha256": hashlib.sha256(open(_eng.LIB_PATH, "rb").read()).hexdigest(), "ch_version": _eng.load_library().ch_version().decode(),
        "collection": "rocprofv3 --kernel-trace --pmc <group>, one group per pass (scripts/profile_round.sh)"}
 allc, launches = {}, 0
 for d in sorted(glob.glob(os.path.join(out, tag + "_pmc_*"))):
