@@ -87,6 +87,15 @@ struct Analysis {
   std::vector<EDev> edev;          // component-ordered
   std::vector<CompClass> classes;
   int max_nc = 0, max_ndev = 0;
+  // tearing (bordered block-diagonal form): a few high-degree unknowns (supply rails behind a resistance) are taken out as the BORDER;
+  // every block carries replicas of them as its last nb local unknowns (local index comp_no[c] + b), so that all per-block tables
+  // keep their shape; devices that touch border unknowns only (the rail resistors) are listed apart
+  int nb = 0;                      // border unknowns (0: not torn)
+  int n_glob = 0;                  // unknowns of the untorn system (own unknowns of all blocks + nb)
+  std::vector<int> comp_no;        // [n_comp] own unknowns of the block (comp_nc = comp_no + nb)
+  std::vector<uint8_t> replica;    // [n_unk] 1 = border replica that is NOT the counted one (block 0 holds the counted replicas)
+  struct BorderDev { int kind; int ta, tb; int hdev; };   // terminals: >= 0 border index, < 0 -(known index + 1)
+  std::vector<BorderDev> border_dev;
   bool force_sparse = false;       // a block has more devices than 16-bit staging offsets address: it takes the sparse path (no dense gather lists)
   bool wide = false;               // a compiled Verilog-A device is present: stamp records are [I(8)|Q(8)|G(64)|C(64)]
   int stride() const { return wide ? 145 : 41; }   // odd number of doubles per record: the lanes of a wave write different LDS banks
@@ -122,7 +131,7 @@ struct UnionFind {
 // protect[d] = true: V source d must keep its branch unknown (its current is observed).
 // swept_src[s] = true: source s has a runtime (per-sample) parameter → never treated as a constant 0 V alias.
 inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSource>& src, const std::vector<char>& protect,
-                   const std::vector<char>& swept_src, Analysis& A) {
+                   const std::vector<char>& swept_src, Analysis& A, bool tear = false) {
   A = Analysis();
   A.n_nodes = n_nodes;
   int nb = 0;
@@ -217,35 +226,63 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     }
   }
 
-  // ---- 3: connected components over provisional unknowns ----
+  // ---- 2b: tearing — up to two unknowns that (almost) every device group hangs on ----
+  std::vector<int> border_of(nprov, -1);
+  int nbord = 0;
+  if (tear) {
+    std::vector<int> deg(nprov, 0);
+    for (const EDev& e : recs) for (int k = 0; k < NTERM; ++k) if (e.term[k] >= 0) deg[e.term[k]]++;
+    std::vector<int> cand;
+    for (int u = 0; u < nprov; ++u) if (deg[u] >= 64) cand.push_back(u);
+    std::sort(cand.begin(), cand.end(), [&](int x, int y) { return deg[x] != deg[y] ? deg[x] > deg[y] : x < y; });
+    if (cand.empty() || cand.size() > 2) { A.err = "tearing: the circuit has no border of one or two high-degree nodes"; return CH_ERR_UNSUPPORTED; }
+    std::sort(cand.begin(), cand.end());
+    for (int u : cand) border_of[u] = nbord++;
+    for (int b = 0; b < nb; ++b) if (prov_branch[b] >= 0 && border_of[prov_branch[b]] >= 0) { A.err = "tearing: a branch current cannot be a border unknown"; return CH_ERR_UNSUPPORTED; }
+  }
+  A.nb = nbord;
+
+  // ---- 3: connected components over the provisional unknowns (the border taken out) ----
   UnionFind cu(nprov);
   std::vector<char> touched(nprov, 0);
   for (const EDev& e : recs) {
     int first = -1;
-    for (int k = 0; k < NTERM; ++k) if (e.term[k] >= 0) { touched[e.term[k]] = 1; if (first < 0) first = e.term[k]; else cu.unite(first, e.term[k]); }
+    for (int k = 0; k < NTERM; ++k) if (e.term[k] >= 0) {
+      touched[e.term[k]] = 1;
+      if (border_of[e.term[k]] >= 0) continue;
+      if (first < 0) first = e.term[k]; else cu.unite(first, e.term[k]);
+    }
   }
   for (int u = 0; u < nprov; ++u) if (!touched[u]) { A.err = "floating node without any device"; return CH_ERR_SINGULAR; }
   std::map<int, int> comp_of_root;
-  std::vector<int> comp_id(nprov);
+  std::vector<int> comp_id(nprov, -1);
   for (int u = 0; u < nprov; ++u) {
+    if (border_of[u] >= 0) continue;
     int r = cu.find(u);
     auto it = comp_of_root.find(r);
     if (it == comp_of_root.end()) it = comp_of_root.insert({r, (int)comp_of_root.size()}).first;
     comp_id[u] = it->second;
   }
   A.n_comp = (int)comp_of_root.size();
+  if (tear && A.n_comp < 2) { A.err = "tearing: removing the border leaves one block"; return CH_ERR_UNSUPPORTED; }
+  A.comp_no.assign(A.n_comp, 0);
+  for (int u = 0; u < nprov; ++u) if (comp_id[u] >= 0) A.comp_no[comp_id[u]]++;
   A.comp_nc.assign(A.n_comp, 0);
-  for (int u = 0; u < nprov; ++u) A.comp_nc[comp_id[u]]++;
+  for (int c = 0; c < A.n_comp; ++c) A.comp_nc[c] = A.comp_no[c] + nbord;
   A.comp_uofs.assign(A.n_comp, 0);
   for (int c = 1; c < A.n_comp; ++c) A.comp_uofs[c] = A.comp_uofs[c - 1] + A.comp_nc[c - 1];
-  // final numbering: component-major, provisional order inside a component
-  std::vector<int> fin(nprov), fill(A.n_comp, 0);
-  for (int u = 0; u < nprov; ++u) { int c = comp_id[u]; fin[u] = A.comp_uofs[c] + fill[c]++; }
-  A.n_unk = nprov;
+  // final numbering: component-major, provisional order inside a component, then the block's replicas of the border
+  std::vector<int> fin(nprov, -1), fill(A.n_comp, 0);
+  for (int u = 0; u < nprov; ++u) if (comp_id[u] >= 0) { int c = comp_id[u]; fin[u] = A.comp_uofs[c] + fill[c]++; }
+  A.n_unk = A.n_comp > 0 ? A.comp_uofs[A.n_comp - 1] + A.comp_nc[A.n_comp - 1] : 0;
+  A.n_glob = nprov;
+  for (int u = 0; u < nprov; ++u) if (border_of[u] >= 0) fin[u] = A.comp_uofs[0] + A.comp_no[0] + border_of[u];   // the counted replica (block 0)
+  A.replica.assign(A.n_unk, 0);
+  for (int c = 1; c < A.n_comp; ++c) for (int b = 0; b < nbord; ++b) A.replica[A.comp_uofs[c] + A.comp_no[c] + b] = 1;
 
   A.node_unknown.assign(n_nodes + 1, -1);
   A.node_known.assign(n_nodes + 1, -1);
-  A.unk_mna.assign(nprov, -1);
+  A.unk_mna.assign(A.n_unk, -1);
   for (int n = 0; n <= n_nodes; ++n) {
     int r = uf.find(n);
     if (known_of[r] >= 0) A.node_known[n] = known_of[r];
@@ -253,13 +290,27 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
   }
   A.branch_unknown.assign(nb, -1);
   for (auto& d : dev) if (d.branch >= 0 && !d.eliminated) { A.branch_unknown[d.branch] = fin[prov_branch[d.branch]]; A.unk_mna[fin[prov_branch[d.branch]]] = n_nodes + d.branch; }
+  for (int c = 1; c < A.n_comp; ++c) for (int b = 0; b < nbord; ++b) A.unk_mna[A.comp_uofs[c] + A.comp_no[c] + b] = A.unk_mna[A.comp_uofs[0] + A.comp_no[0] + b];
 
   // ---- devices per component (component-major order) ----
   std::vector<std::vector<int>> cdev(A.n_comp);
   for (size_t i = 0; i < recs.size(); ++i) {
     EDev& e = recs[i];
     int c = -1;
-    for (int k = 0; k < NTERM; ++k) if (e.term[k] >= 0) { c = comp_id[e.term[k]]; e.term[k] = fin[e.term[k]]; }
+    bool any_unknown = false;
+    for (int k = 0; k < NTERM; ++k) if (e.term[k] >= 0) { any_unknown = true; if (border_of[e.term[k]] < 0) c = comp_id[e.term[k]]; }
+    if (c < 0 && any_unknown) {
+      // every unknown terminal is a border unknown: a two-terminal linear element of the border itself (the rail resistance,
+      // a decoupling capacitor to ground or between the rails); its stamps are added to the reduced system by every wavefront
+      const bool cap_ok = e.kind == K_C && (e.term[0] >= 0 || e.term[0] == -1) && (e.term[1] >= 0 || e.term[1] == -1);
+      if (!(e.kind == K_R || cap_ok)) { A.err = "tearing: a device other than a resistor or a grounded / rail-to-rail capacitor sits on the border alone"; return CH_ERR_UNSUPPORTED; }
+      Analysis::BorderDev bd; bd.kind = e.kind; bd.hdev = e.hdev;
+      bd.ta = e.term[0] >= 0 ? border_of[e.term[0]] : e.term[0];
+      bd.tb = e.term[1] >= 0 ? border_of[e.term[1]] : e.term[1];
+      A.border_dev.push_back(bd);
+      continue;
+    }
+    for (int k = 0; k < NTERM; ++k) if (e.term[k] >= 0) e.term[k] = border_of[e.term[k]] >= 0 ? A.comp_uofs[c] + A.comp_no[c] + border_of[e.term[k]] : fin[e.term[k]];
     if (c >= 0) cdev[c].push_back((int)i);  // devices between known nodes only do not enter the system
   }
   A.comp_dofs.assign(A.n_comp, 0);
@@ -271,6 +322,7 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     A.max_nc = std::max(A.max_nc, A.comp_nc[c]);
     A.max_ndev = std::max(A.max_ndev, A.comp_ndev[c]);
   }
+  if (tear && A.max_nc > 16) { A.err = "tearing: a block with its border replicas has more than 16 unknowns"; return CH_ERR_UNSUPPORTED; }
   // differential mask
   A.diff_mask.assign(A.n_unk, 0);
   for (const EDev& e : A.edev) {
@@ -279,6 +331,13 @@ inline int analyse(int n_nodes, std::vector<HDev>& dev, const std::vector<HSourc
     else if (e.kind == K_L) mark(e.term[2]);
     else if (e.kind == K_MOS) for (int k = 0; k < 4; ++k) mark(e.term[k]);
     else if (e.kind == K_VA) for (int k = 0; k < e.nt; ++k) if (e.qmask & (1u << k)) mark(e.term[k]);
+  }
+
+  if (nbord > 0) {   // a border unknown is differential when any block (or a border capacitor) says so; every replica carries the flag
+    std::vector<uint8_t> bd(nbord, 0);
+    for (int c = 0; c < A.n_comp; ++c) for (int b = 0; b < nbord; ++b) bd[b] |= A.diff_mask[A.comp_uofs[c] + A.comp_no[c] + b];
+    for (const auto& d : A.border_dev) if (d.kind == K_C) { if (d.ta >= 0) bd[d.ta] = 1; if (d.tb >= 0) bd[d.tb] = 1; }
+    for (int c = 0; c < A.n_comp; ++c) for (int b = 0; b < nbord; ++b) A.diff_mask[A.comp_uofs[c] + A.comp_no[c] + b] = bd[b];
   }
 
   // ---- 4: classes + gather lists ----

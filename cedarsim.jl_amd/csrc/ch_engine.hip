@@ -247,6 +247,13 @@ struct ch_circuit {
   NewtonArgs base;              // structure pointers filled once
   // ---- sparse path (blocks too large for LDS) ----
   int path = 1;                 // 1 = fused block kernel, 2 = sparse level-scheduled LU
+  // A coupled array behind a border of one or two unknowns (supply rails with a series resistance): the same description analysed
+  // with tearing (ch_analysis.hpp) — independent blocks + border replicas.  It only ever runs transients on the device-resident
+  // stepper, started from this circuit's (sparse-path) operating point; everything else stays on this circuit.
+  std::unique_ptr<ch_circuit> torn_c;
+  bool is_torn = false;
+  std::string torn_note;
+  std::vector<double> h_dpar0, h_dmult0;   // main parameter and multiplicity of every device as uploaded (sample 0)
   SparsePlan plan[2];           // [0] DC (alpha0 = 0), [1] transient
   struct PlanDev { DevBuf<int> prow, pcol, a2lu, diag_pos, lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows, lrow_ptr, l_pos, l_k, l_upd_ptr, upd_dst, upd_src, urow_ptr, u_pos, u_col;
                    DevBuf<int> lu2a, la_pos, la_diag, lb_dst, lb_sptr, lb_l, lb_u, lb_d, fl_rows, bl_rows; DevBuf<double> LUv, Lv; } plan_dev[2];
@@ -373,7 +380,7 @@ struct ch_circuit {
       HIPCHK(d_dvac.upload(dvac, st)); HIPCHK(d_va_mod.upload(vmod, st)); HIPCHK(d_va_pofs.upload(vpofs, st)); HIPCHK(d_va_cofs.upload(vcofs, st));
     }
     std::vector<unsigned char> dm(A.n_unk, 0);
-    for (int u = 0; u < A.n_unk; ++u) dm[u] = (A.diff_mask[u] ? 1 : 0) | (A.unk_mna[u] >= n_nodes ? 2 : 0);
+    for (int u = 0; u < A.n_unk; ++u) dm[u] = (A.diff_mask[u] ? 1 : 0) | (A.unk_mna[u] >= n_nodes ? 2 : 0) | (A.replica[u] ? 4 : 0);   // bit 2: border replica outside block 0 (not counted in norms)
     std::vector<int> obs_unk, unk_obs(A.n_unk, -1);
     obs_primary.clear();
     for (size_t o = 0; o < obs_kind.size(); ++o) {
@@ -459,6 +466,8 @@ struct ch_circuit {
         }
       }
     }
+    h_dpar0.assign(nh, 0.0); h_dmult0.assign(nh, 1.0);
+    for (int i = 0; i < nh; ++i) { h_dpar0[i] = hpar[(size_t)i * Spar]; h_dmult0[i] = hmult[(size_t)i * Spar]; }
     HIPCHK(d_dpar.upload(hpar, st)); HIPCHK(d_dmult.upload(hmult, st)); HIPCHK(d_gmin.upload(hg, st)); HIPCHK(d_temp.upload(htemp, st));
     {  // Verilog-A parameter blocks: one copy, or one per sample when a CH_SLOT_VA_PAR slot is set
       bool any_va = false;
@@ -1087,6 +1096,7 @@ struct ch_circuit {
     if (Ssrc != 1) return no("per-sample source parameters");
     if (needed_src.size() > (size_t)P_MAXSRC || A.known.size() + (size_t)n_dev_src() > 64) return no("more than 64 sources / known-node and source values per attempt");
     if (!(S == 1 || A.n_comp == 1)) return no("several blocks per sample in a multi-sample batch");
+    if (A.nb > 0 && (S != 1 || A.border_dev.size() > 8)) return no("bordered form: one sample and at most 8 devices on the border alone");
     for (const ClassMeta& m : h_cms) if (m.nslots > 64 || m.nc > lu_variant || m.n_work <= 0) return no("a block class does not fit the one-wave register path");
     if (n_cu == 0) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return no("hipGetDeviceProperties failed"); n_cu = prop.multiProcessorCount; }
     const long nblk = (long)A.n_comp * S;
@@ -1154,6 +1164,12 @@ struct ch_circuit {
     pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz
     // a batch of single-block samples on a common output grid: every sample its own step sequence (no lock-step, no grid reduction)
     pa.indep = persist_own_steps(o) ? 1 : 0;
+    pa.nb = A.nb; pa.n_glob = A.n_glob; pa.n_bdev = (int)A.border_dev.size();
+    for (int q = 0; q < pa.n_bdev; ++q) {
+      const Analysis::BorderDev& bd = A.border_dev[q];
+      pa.bd_kind[q] = bd.kind; pa.bd_ta[q] = bd.ta; pa.bd_tb[q] = bd.tb;
+      pa.bd_val[q] = bd.kind == K_R ? h_dmult0[bd.hdev] / h_dpar0[bd.hdev] : h_dmult0[bd.hdev] * h_dpar0[bd.hdev];
+    }
     const bool coop = !pa.indep || nblk <= PW * n_cu;   // without grid-wide waits the workgroups may queue behind each other
     pa.pair_dbg = std::getenv("CEDARHIP_PAIR_DBG") ? std::atoi(std::getenv("CEDARHIP_PAIR_DBG")) : 0;
     // initial controller state (same first step as the host stepper)
@@ -1224,8 +1240,48 @@ struct ch_circuit {
     return finish_tran(R, 0, cs.t, status, tstart);
   }
 
+  // A coupled array behind a border of one or two unknowns: operating point on this circuit (sparse path), transient on the torn
+  // companion's device-resident stepper.  used = false: the companion does not take the problem (reason in torn_note).
+  int tran_torn(double t0, double t1, const ch_tran_opts& o, ch_result& R, bool& used) {
+    used = false;
+    auto tstart = hclock::now();
+    int rc = finalize_params();
+    if (rc != CH_OK) return rc;
+    std::vector<double> x_mna((size_t)S * A.n_mna, 0.0);
+    ch_stats dcst; std::memset(&dcst, 0, sizeof(dcst));
+    device_ms = 0; n_launch = 0; n_timed = 0;
+    if (o.skip_dc) { if (o.dc.x0) std::copy(o.dc.x0, o.dc.x0 + x_mna.size(), x_mna.begin()); }
+    else {
+      rc = dc_solve(o.dc, 0, nullptr, &dcst);
+      if (rc != CH_OK) { used = true; return rc; }
+      rc = download_mna(0, t0, 1, x_mna.data());
+      if (rc != CH_OK) return rc;
+    }
+    const double dc_s = std::chrono::duration<double>(hclock::now() - tstart).count();
+    const long dc_l = n_launch;
+    ch_tran_opts o2 = o; o2.skip_dc = 1; o2.dc.x0 = x_mna.data(); o2.stepper = CH_STEPPER_DEVICE;
+    ch_circuit* tc = torn_c.get();
+    { ArenaScope sc(&tc->arena); rc = tc->tran_solve(t0, t1, o2, R); }
+    if (rc == CH_ERR_UNSUPPORTED) { torn_note = err(); ctx->err.clear(); return CH_OK; }
+    used = true;
+    R.stats.dc_seconds = dc_s; R.stats.wall_seconds += dc_s; R.stats.n_kernel_launches += dc_l;
+    R.stats.nf += dcst.nf; R.stats.njacs += dcst.njacs; R.stats.nfactors += dcst.nfactors; R.stats.nsolve += dcst.nsolve;
+    R.stats.nnonliniter += dcst.nnonliniter; R.stats.nrestarts += dcst.nrestarts; R.stats.n_block_iters += dcst.n_block_iters;
+    return rc;
+  }
+
   // ------------------------------------------------------------------------------------------
   int tran_solve(double t0, double t1, const ch_tran_opts& o, ch_result& R) {
+    if (torn_c && !is_torn && S == 1 && std::getenv("CEDARHIP_NO_TEAR") == nullptr) {
+      const char* ev = std::getenv("CEDARHIP_STEPPER");
+      int want = o.stepper;
+      if (want == CH_STEPPER_AUTO && ev) want = std::strcmp(ev, "host") == 0 ? CH_STEPPER_HOST : CH_STEPPER_AUTO;
+      if (want != CH_STEPPER_HOST) {
+        bool used = false;
+        const int rc = tran_torn(t0, t1, o, R, used);
+        if (used || rc != CH_OK) return rc;
+      }
+    }
     auto tstart = hclock::now();
     std::memset(&R.stats, 0, sizeof(R.stats));
     R.S = S; R.n_obs = (int)obs_kind.size();
@@ -1286,8 +1342,9 @@ struct ch_circuit {
           if (used) return rc;
           why = err();
         }
-        if (want == CH_STEPPER_DEVICE) { set_err("device-resident stepper not available for this circuit: " + why); return CH_ERR_UNSUPPORTED; }
+        if (want == CH_STEPPER_DEVICE || is_torn) { set_err("device-resident stepper not available for this circuit: " + why); return CH_ERR_UNSUPPORTED; }
       }
+      if (is_torn) { set_err("the torn form of a circuit runs on the device-resident stepper only"); return CH_ERR_UNSUPPORTED; }
     }
 
     // saved observables live on the device until the end
@@ -1532,7 +1589,7 @@ static ch_ctx* ch_create_impl(int device_id, char* err, size_t errlen) {
 void ch_destroy(ch_ctx* c) { if (!c) return; if (c->stream) (void)hipStreamDestroy(c->stream); delete c; }
 const char* ch_last_error(ch_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
-static ch_circuit* ch_circuit_build_impl(ch_ctx* ctx, const ch_desc* d) {
+static ch_circuit* ch_circuit_build_impl(ch_ctx* ctx, const ch_desc* d, bool tear = false) {
   if (!ctx || !d) return nullptr;
   ctx->err.clear();
   (void)hipSetDevice(ctx->device);
@@ -1592,10 +1649,17 @@ static ch_circuit* ch_circuit_build_impl(ch_ctx* ctx, const ch_desc* d) {
   }
   // an AC-driven voltage source keeps its node and branch unknowns: the small-signal excitation enters one linear row
   for (size_t i = 0; i < c->dev.size(); ++i) if (c->dev[i].kind == CH_DEV_V && c->src[c->dev[i].ipar[0]].ac != 0.0) { protect[i] = 1; swept[c->dev[i].ipar[0]] = 1; }
-  int rc = analyse(c->n_nodes, c->dev, c->src, protect, swept, c->A);
+  int rc = analyse(c->n_nodes, c->dev, c->src, protect, swept, c->A, tear);
   if (rc != CH_OK) { ctx->err = c->A.err; return nullptr; }
+  c->is_torn = tear;
   rc = c->upload_structure();
   if (rc != CH_OK) return nullptr;
+  if (!tear && c->A.max_nc > 64 && std::getenv("CEDARHIP_NO_TEAR") == nullptr) {
+    // one large coupled block: try the bordered block-diagonal form (refused, with a reason, for most circuits)
+    c->torn_c.reset(ch_circuit_build_impl(ctx, d, true));
+    c->torn_note = c->torn_c ? "torn companion built" : ctx->err;
+    ctx->err.clear();
+  }
   return owner.release();
 }
 void ch_circuit_free(ch_circuit* c) { delete c; }
@@ -1623,6 +1687,7 @@ static int ch_set_samples_impl(ch_circuit* c, int32_t n) {
   c->S = n;
   for (auto& v : c->slot_val) v.clear();
   c->dirty = true;
+  if (c->torn_c) return ch_set_samples_impl(c->torn_c.get(), n);
   return CH_OK;
 }
 static int ch_set_params_impl(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_slots, const int32_t* ids, const double* values) {
@@ -1649,6 +1714,7 @@ static int ch_set_params_impl(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_s
     for (int s = lo; s < hi; ++s) v[s] = values[(size_t)i * (hi - lo) + (s - lo)];
   }
   c->dirty = true;
+  if (c->torn_c) return ch_set_params_impl(c->torn_c.get(), lo, hi, n_slots, ids, values);
   return CH_OK;
 }
 

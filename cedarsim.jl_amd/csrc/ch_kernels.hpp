@@ -414,6 +414,54 @@ __device__ __forceinline__ bool lu_solve_regs(double (&r)[NC + 1], int nc, int l
   return true;
 }
 
+// Bordered block-diagonal form (ch_analysis.hpp, tearing): the block's last nb rows / columns are its replicas of the border
+// unknowns.  lu_bbd_factor eliminates the block's OWN unknowns only (pivots among lanes < no, columns 0..no-1) from every row,
+// the border rows included: what is left in the border lanes, columns no..nc, is this block's contribution [S_i | g_i] to the
+// Schur complement on the border.  After the contributions of all blocks have been summed and the border solved (dxb),
+// lu_bbd_back substitutes back through the block's pivot rows.  Same pivot rule and broadcasts as lu_solve_regs.
+template <int NC>
+__device__ __forceinline__ bool lu_bbd_factor(double (&r)[NC + 1], int no, int nc, int lane, int (&piv)[NC], int& mystep, double& ipiv) {
+  bool done = lane >= nc;
+  mystep = -1; ipiv = 0.0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    piv[k] = 0;
+    if (k < no) {
+      const int hi = __double2hiint(r[k]) & 0x7fffffff;
+      const int key = (done || lane >= no) ? -1 : ((hi & ~63) | (63 - lane));
+      const int best = __builtin_amdgcn_readfirstlane(row_max_i<NC>(key));
+      if (best < 64 || best >= 0x7e300000) return false;
+      const int bi = 63 - (best & 63);
+      piv[k] = bi;
+      const double ipk = frcp(bcast(r[k], bi));
+      const double l = (!done && lane != bi) ? r[k] * ipk : 0.0;
+#pragma unroll
+      for (int j = k + 1; j <= NC; ++j) r[j] = fma(-l, bcast(r[j], bi), r[j]);
+      if (lane == bi) { done = true; mystep = k; ipiv = ipk; }
+    }
+  }
+  return true;
+}
+// r[] as left by lu_bbd_factor; dxb0 / dxb1 = the border solution (wave-uniform).  On return lane i < no holds dx_i, lane no + b holds dxb_b.
+template <int NC>
+__device__ __forceinline__ double lu_bbd_back(const double (&r)[NC + 1], int no, int nc, int lane, const int (&piv)[NC], int mystep, double ipiv, double dxb0, double dxb1) {
+  double rhs = 0.0, c0 = 0.0, c1 = 0.0;
+#pragma unroll
+  for (int j = 0; j <= NC; ++j) { if (j == nc) rhs = r[j]; if (j == no) c0 = r[j]; if (j == no + 1 && j < nc) c1 = r[j]; }
+  rhs = fma(-c0, dxb0, rhs);
+  rhs = fma(-c1, dxb1, rhs);
+  double out = lane == no ? dxb0 : (lane == no + 1 ? dxb1 : 0.0);
+#pragma unroll
+  for (int k = NC - 1; k >= 0; --k) {
+    if (k < no) {
+      const double xk = bcast(rhs * ipiv, piv[k]);
+      if (lane == k) out = xk;
+      if (mystep >= 0 && mystep < k) rhs = fma(-r[k], xk, rhs);
+    }
+  }
+  return out;
+}
+
 // LDS fallback for blocks larger than the register variant (single wave, barriers are wave-local fences)
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 __device__ inline bool lu_solve_lds(double* A, int lda, int nc, int lane) {

@@ -59,6 +59,13 @@ struct PersistArgs {
   int pair_dbg;               // diagnostic: 1 = the first wave of a pair evaluates both halves itself (A/B of the function split)
   int indep;                  // 1: a batch of single-block samples on a common saveat grid — every sample (pair of samples when PAIR)
                               //    runs its own controller: no grid-wide reduction at all, each takes exactly the steps it needs
+  // Bordered block-diagonal form (a coupled array torn at its supply rails, ch_analysis.hpp): every block's last nb local unknowns
+  // are replicas of the border unknowns.  Per Newton iteration: partial LU of every block, grid-wide SUM of the blocks' Schur
+  // contributions, the nb x nb border system solved by every wave, back substitution; a second reduction carries the update
+  // norm and the local-error sums, so convergence and step acceptance are decided from the same global numbers by every wave.
+  int nb, n_glob, n_bdev;     // border unknowns (0: independent blocks), unknowns of the untorn system, devices on the border alone
+  int bd_kind[8], bd_ta[8], bd_tb[8];   // K_R / K_C; terminals: >= 0 border index, < 0 -(known index + 1)
+  double bd_val[8];           // conductance / capacitance, multiplicity included
 };
 
 // ---- constants blob layout -------------------------------------------------------------------
@@ -209,9 +216,9 @@ __device__ __forceinline__ p_u64 p_split(double v, int lane, unsigned gen) {
   return ((p_u64)gen << 32) | half;
 }
 __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const double* rec /* 8 wave-uniform values */, double* part, double* summ,
-                                     int* s_abort, int wave, int lane, int wg) {
+                                     int* s_abort, int wave, int lane, int wg, bool all_sum = false) {
   const int g16 = lane & 15, f = g16 >> 1, m4 = lane >> 4;   // granule of the record, its field, member slot of a sweep
-  const bool fmaxop = (f == 4) || (p.red_max && f < 3);
+  const bool fmaxop = !all_sum && ((f == 4) || (p.red_max && f < 3));
   if (lane < P_NREC) {
     double v = rec[0];
 #pragma unroll
@@ -572,27 +579,34 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     double rate_new = -1.0, dn_prev = 0.0;
     const double rp = reset_rate ? 1.0 : rate_prev;
     bool done_own = !live;
-    if (live || PAIR) {
-      for (int it = 0; PAIR || it <= a.maxit; ++it) {
+    const bool bbd = p.nb > 0;
+    const int no = nc - p.nb;                            // the block's own unknowns; lanes no .. nc-1 hold its border replicas
+    bool stop_all = false, abort_all = false;            // bordered form: grid-uniform decisions
+    double bA = 0.0, bB = 0.0, bC = 0.0, bN = 0.0;       // bordered form: the local-error sums of the last iteration's reduction
+    if (live || PAIR || bbd) {
+      for (int it = 0; PAIR || bbd || it <= a.maxit; ++it) {
+        if (bbd && stop_all) break;
         if (PAIR) {
           if (lane == 0) pf[2 + role] = done_own ? 1 : 0;
           pair_sync();                                   // both iterates (or their done flags) are in LDS
           const int d0 = pf[2], d1 = pf[3];
-          if ((d0 && d1) || pair_broken) break;
+          if (!bbd && ((d0 && d1) || pair_broken)) break;
           if (!(half ? d1 : d0)) {
             if (role == 0) eval_cached<0>(smeta, gmin_h, xl_h, kvl, svl, pl_h, st_h);
             if (role == 1 ? (p.pair_dbg & 1) == 0 : (p.pair_dbg & 1) == 1) eval_cached<1>(smeta, gmin_h, xl_h, kvl, svl, pl_h, st_h);
           }
           pair_sync();                                   // both halves of every stamp record are in LDS
           P_STAMP(4);   // device evaluation (one half of it)
-          if (pair_broken) break;
-          if (done_own) continue;
+          if (!bbd) {
+            if (pair_broken) break;
+            if (done_own) continue;
+          }
         } else {
-        eval_cached<-1>(smeta, gmin_h, xl, kvl, svl, pl, st);
+        if (live) eval_cached<-1>(smeta, gmin_h, xl, kvl, svl, pl, st);
         lds_fence();
         P_STAMP(4);   // device evaluation
         }
-        for (int w = lane; w < cm.n_work; w += 64) {
+        for (int w = lane; w < (live ? cm.n_work : 0); w += 64) {
           const int2 itw = wl[w];
           const int p0 = itw.x, pe = p0 + (int)((unsigned)itw.y >> 16), e = itw.y & 0x7fff;
           const bool vec = itw.y & 0x8000;
@@ -628,6 +642,112 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         for (int j = 0; j < NCR; ++j) cr[j] = (mine && j < nc) ? Cm[lane * nc + j] : 0.0;
         const double Fi = mine ? Fv[lane] : 0.0, Qi = mine ? Qv[lane] : 0.0, xi = mine ? xl[lane] : 0.0, wi = mine ? wv[lane] : 0.0;
         const double fnorm = bcast(row_max<NCR>(fabs(Fi)), 0);
+        if (bbd) {
+          // ---- (a) partial LU of the block, this block's Schur contribution, grid-wide sum ----
+          bool lfail = live && (!(fnorm == fnorm) || fnorm > 1e300);
+          int piv[NCR]; int mystep; double ipiv;
+          if (!lu_bbd_factor<NCR>(r, no, nc, lane, piv, mystep, ipiv)) lfail = live;
+          double srec[P_NREC];
+          {
+            double c0 = 0.0, c1 = 0.0, cr_ = 0.0;   // this lane's entries in the border columns and the right-hand side
+#pragma unroll
+            for (int j = 0; j <= NCR; ++j) { if (j == no) c0 = r[j]; if (j == no + 1 && j < nc) c1 = r[j]; if (j == nc) cr_ = r[j]; }
+            const bool use = live && !lfail;
+            srec[0] = use ? bcast(c0, no) : 0.0; srec[1] = use ? bcast(c1, no) : 0.0; srec[2] = use ? bcast(cr_, no) : 0.0;
+            const int l1 = p.nb > 1 ? no + 1 : no;
+            srec[3] = (use && p.nb > 1) ? bcast(c0, l1) : 0.0; srec[4] = (use && p.nb > 1) ? bcast(c1, l1) : 0.0; srec[5] = (use && p.nb > 1) ? bcast(cr_, l1) : 0.0;
+            srec[6] = lfail ? 1.0 : 0.0; srec[7] = pair_broken ? 1.0 : 0.0;
+          }
+          ++gen;
+          const long long cbA = wall_clock64();
+          bool okr = p_grid_reduce(p, gen, srec, part, summ, &s_abort, wave, lane, wg, true);
+          double S00 = summ[0], S01 = summ[1], g0 = summ[2], S10 = summ[3], S11 = summ[4], g1 = summ[5];
+          const bool gfail = summ[6] != 0.0;
+          if (!okr || summ[7] != 0.0) abort_all = true;
+          __syncthreads();   // summ is rewritten by the next reduction
+          cyc_bar += wall_clock64() - cbA;
+          if (abort_all) break;
+          if (gfail) { nstat = 2; break; }
+          // ---- (b) the devices that sit on the border alone (rail resistance, decoupling capacitors): every wave adds them ----
+          {
+            const double xb0 = xl[no], xb1 = p.nb > 1 ? xl[no + 1] : 0.0;
+            // history term of the border charges: sum_j alpha_j * C (xb_a - xb_b)(t_j) from the ring of the replicas (linear elements)
+            double hb0 = 0.0, hb1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              const int sl = (head - j) & 7;
+              const double w = (j < kk) ? coef[j + 1] : 0.0;
+              hb0 = fma(w, (j < kk) ? Xh[sl * nc + no] : 0.0, hb0);
+              if (p.nb > 1) hb1 = fma(w, (j < kk) ? Xh[sl * nc + no + 1] : 0.0, hb1);
+            }
+            for (int q = 0; q < p.n_bdev; ++q) {
+              const int ta = p.bd_ta[q], tb = p.bd_tb[q];
+              const double va = ta >= 0 ? (ta == 0 ? xb0 : xb1) : kvl[-ta - 1], vb = tb >= 0 ? (tb == 0 ? xb0 : xb1) : kvl[-tb - 1];
+              double gj, f;   // Jacobian entry and residual current of the element, a -> b
+              if (p.bd_kind[q] == K_R) { gj = p.bd_val[q]; f = gj * (va - vb); }
+              else {            // capacitor (terminals: border or ground): alpha0 q + history
+                const double ha = ta >= 0 ? (ta == 0 ? hb0 : hb1) : 0.0, hb = tb >= 0 ? (tb == 0 ? hb0 : hb1) : 0.0;
+                gj = alpha0 * p.bd_val[q]; f = gj * (va - vb) + p.bd_val[q] * (ha - hb);
+              }
+              // rows: J dx = -F
+              if (ta == 0) { S00 += gj; g0 -= f; if (tb == 1) S01 -= gj; }
+              if (ta == 1) { S11 += gj; g1 -= f; if (tb == 0) S10 -= gj; }
+              if (tb == 0) { S00 += gj; g0 += f; if (ta == 1) S01 -= gj; }
+              if (tb == 1) { S11 += gj; g1 += f; if (ta == 0) S10 -= gj; }
+            }
+          }
+          // ---- (c) the border system ----
+          double dxb0, dxb1 = 0.0;
+          if (p.nb > 1) {
+            const double det = S00 * S11 - S01 * S10;
+            dxb0 = (g0 * S11 - S01 * g1) / det; dxb1 = (S00 * g1 - S10 * g0) / det;
+          } else dxb0 = g0 / S00;
+          if (!(fabs(dxb0) < 1e300) || !(fabs(dxb1) < 1e300)) { nstat = 2; break; }   // singular border (uniform: every wave holds the same numbers)
+          // ---- (d) back substitution, update, charges, norms ----
+          double e2own = 0.0, l2k = 0.0, l2m = 0.0, l2p = 0.0, lnd = 0.0, lbad = 0.0;
+          if (live) {
+            const double dx = lu_bbd_back<NCR>(r, no, nc, lane, piv, mystep, ipiv, dxb0, dxb1);
+            const double xn = xi + dx;
+            if (mine) xl[lane] = xn;
+            const bool bad = mine && (!(xn == xn) || fabs(xn) > 1e300);
+            double q = Qi;
+#pragma unroll
+            for (int j = 0; j < NCR; ++j) if (j < nc) q = fma(cr[j], bcast(dx, j), q);
+            if (mine) qn[lane] = q;
+            const bool counted = mine && !(dml[lane] & 4);   // own unknowns, and block 0's replicas of the border
+            const double tq = dx * wi;
+            e2own = bcast(row_sum<NCR>(counted ? tq * tq : 0.0), 0);
+            lbad = __ballot(bad) ? 1.0 : 0.0;
+            double v2k = 0.0, v2m = 0.0, v2p = 0.0, vnd = 0.0;
+            if (counted && (dml[lane] & 1)) {
+              const double w = 1.0 / (a.reltol * fmax(fabs(x0), fabs(xn)) + a.abstol);
+              vnd = 1.0;
+              double tq2 = (xn - xp[lane]) * w; v2k = tq2 * tq2;
+              if (nkm1 > 0) { tq2 = (xn - pm[lane]) * w; v2m = tq2 * tq2; }
+              if (nkp1 > 0) { tq2 = (xn - pp[lane]) * w; v2p = tq2 * tq2; }
+            }
+            l2k = bcast(row_sum<16>(v2k), 0); l2m = bcast(row_sum<16>(v2m), 0); l2p = bcast(row_sum<16>(v2p), 0); lnd = bcast(row_sum<16>(vnd), 0);
+          }
+          ++iters;
+          double brec[P_NREC] = {l2k, l2m, l2p, lnd, e2own, lbad, 0.0, pair_broken ? 1.0 : 0.0};
+          ++gen;
+          const long long cbB = wall_clock64();
+          okr = p_grid_reduce(p, gen, brec, part, summ, &s_abort, wave, lane, wg, true);
+          bA = summ[0]; bB = summ[1]; bC = summ[2]; bN = summ[3];
+          const double e2g = summ[4]; const bool gbad = summ[5] != 0.0;
+          if (!okr || summ[7] != 0.0) abort_all = true;
+          __syncthreads();
+          cyc_bar += wall_clock64() - cbB;
+          if (abort_all) break;
+          if (gbad) { nstat = 2; break; }
+          const double dn = sqrt(e2g / (double)p.n_glob);
+          if (it == 0) { if (dn <= a.newton_tol || (rp < 0.9 && 2.0 * fmax(rp, 0.02) * dn <= a.newton_tol)) { nstat = 0; stop_all = true; } }
+          else { rate_new = dn_prev > 0.0 ? dn / dn_prev : 0.0; if (dn <= a.newton_tol) { nstat = 0; stop_all = true; } }
+          dn_prev = dn;
+          if (it + 1 >= a.maxit) stop_all = true;   // not converged within maxit: nstat stays 1
+          lds_fence();
+          continue;
+        }
         bool stop = false;
         if (!(fnorm == fnorm) || fnorm > 1e300) { nstat = 2; stop = true; }
         else if (it == a.maxit) { stop = true; }
@@ -677,14 +797,14 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       }
     }
     e2k = bcast(row_sum<16>(e2k), 0); e2m = bcast(row_sum<16>(e2m), 0); e2p = bcast(row_sum<16>(e2p), 0); ndf = bcast(row_sum<16>(ndf), 0);
-    if (live && nstat == 0) rate_prev = iters >= 2 ? fmin(1.0, fmax(rate_new, 1e-4)) : fmin(1.0, rp * 1.5);
+    if ((live || bbd) && nstat == 0) rate_prev = iters >= 2 ? fmin(1.0, fmax(rate_new, 1e-4)) : fmin(1.0, rp * 1.5);   // bordered form: the same in every wave
     double rec[P_NREC];
     if (p.red_max) { const double inv = ndf > 0.0 ? 1.0 / ndf : 0.0; rec[0] = e2k * inv; rec[1] = e2m * inv; rec[2] = e2p * inv; }
     else { rec[0] = e2k; rec[1] = e2m; rec[2] = e2p; }
     rec[3] = ndf; rec[4] = (double)iters; rec[5] = (double)iters; rec[6] = (live && nstat != 0) ? 1.0 : 0.0; rec[7] = 0.0;
     if (!live) { for (int q = 0; q < P_NREC; ++q) rec[q] = 0.0; }
     if (pair_broken) rec[7] = 1.0;   // a pair wait ran into its bound: every wave of the grid leaves at this attempt
-    ++gen;
+    if (!bbd) ++gen;   // (the bordered form has made its reductions inside the Newton loop: consecutive reductions must alternate parity)
     P_STAMP(9);   // candidate, local-error sums
     const long long cb0 = wall_clock64();
     double sA, sB, sC, sN, sItMax, sItSum, sFail;
@@ -707,6 +827,10 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       }
       sA = r8[0]; sB = r8[1]; sC = r8[2]; sN = r8[3]; sItMax = r8[4]; sItSum = (double)iters; sFail = r8[6];
       if (r8[7] != 0.0) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
+    } else if (bbd) {
+      // the last iteration's reduction already carried the local-error sums; every wave holds the same Newton outcome
+      if (abort_all) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
+      sA = bA; sB = bB; sC = bC; sN = bN; sItMax = (double)iters; sItSum = (double)iters * (double)p.nblk; sFail = nstat != 0 ? 1.0 : 0.0;
     } else {
       const bool okr = p_grid_reduce(p, gen, rec, part, summ, &s_abort, wave, lane, wg);
       if (!okr || summ[7] != 0.0) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }

@@ -81,14 +81,17 @@ def dff_array(n_tiles=1, skew=None, observe="q", gmin=1e-15, supply_r=None):
     c = Circuit(gmin=gmin)
     m = gf180_models()
     mi = {"n": c.add_model(*m["nfet_06v0"]), "p": c.add_model(*m["pfet_06v0"])}
-    if supply_r is None:
+    r_vdd, r_vss = supply_r if isinstance(supply_r, (tuple, list)) else (supply_r, supply_r)   # a pair: one rail may stay ideal
+    if r_vdd is None:
         c.V("vvdd", "vdd", 0, dc=5.0)
-        c.V("vvss", "vss", 0, dc=0.0)
     else:
         c.V("vvdd", "vdd_src", 0, dc=5.0)
-        c.R("rvdd", "vdd_src", "vdd", float(supply_r))
+        c.R("rvdd", "vdd_src", "vdd", float(r_vdd))
+    if r_vss is None:
+        c.V("vvss", "vss", 0, dc=0.0)
+    else:
         c.V("vvss", "vss_src", 0, dc=0.0)
-        c.R("rvss", "vss_src", "vss", float(supply_r))
+        c.R("rvss", "vss_src", "vss", float(r_vss))
     c.V("vnw", "vnw", "vdd", dc=0.0)
     c.V("vpw", "vpw", "vss", dc=0.0)
     if skew is None:
