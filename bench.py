@@ -275,6 +275,24 @@ def main():
                                             "accepted_steps": st_s["naccept"], "rejected_steps": st_s["nreject"], "step_attempts": st_s["n_step_attempts"],
                                             "step_controller": "device-resident" if st_s["stepper"] == 2 else "host",
                                             "every_tile_meets_reference_gate": bool(np.max(np.abs(qs - np.array(DFF_CHECK_Q)[None, :])) <= 10 * TOL)}
+        if world == 1 and not args.no_skew and args.tiles == N_TILES:
+            # The same array behind NON-IDEAL rails (1 ohm in series with VDD and VSS): structurally ONE coupled block of 11 266
+            # unknowns — "assembly + LU refactor" of BASELINE.json config 3 taken literally.  The engine tears it at the two rail
+            # unknowns: register LU per tile + Schur complement on the rails inside the device-resident stepper, DC on the sparse
+            # path.  A third, separate measurement: NOT `value`.
+            cc = dff_array(args.tiles, observe="q", supply_r=1.0)
+            ec = EngineCircuit(cc, ctx)
+            ec.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+            t0c = time.perf_counter()
+            rc_c, t_c, v_c, _, st_c = ec.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+            el_c = time.perf_counter() - t0c
+            qc = np.array([[np.interp(tt, t_c, v_c[k, :, 0]) for tt in DFF_CHECK_TIMES] for k in range(v_c.shape[0])])
+            ic = ec.info()
+            line["coupled_rails_variant"] = {"workload": "same array, 1 ohm in series with the VDD and VSS sources (one coupled block, %d unknowns, nnz(J) %d)" % (ic["n_unknowns"], ic["nnz_jac"]),
+                                             "rc": rc_c, "ms_per_transient": 1e3 * el_c, "dc_ms": 1e3 * st_c["dc_seconds"], "newton_iters_per_sec": st_c["nnonliniter"] / el_c,
+                                             "accepted_steps": st_c["naccept"], "rejected_steps": st_c["nreject"], "step_attempts": st_c["n_step_attempts"],
+                                             "solver": "torn at the rails: register LU per tile + Schur complement, device-resident stepper" if st_c["stepper"] == 2 else "sparse path (level-synchronous LU), host stepper",
+                                             "every_tile_meets_reference_gate": bool(np.max(np.abs(qc - np.array(DFF_CHECK_Q)[None, :])) <= 10 * TOL)}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         else:

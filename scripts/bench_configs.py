@@ -87,24 +87,38 @@ if only in ("all", "config4_share"):
                                      "block_iterations_per_second": st["n_block_iters"] / el, "samples_passing_reference_gate": int(ok.all(axis=0).sum())}
     out["config4_share_mc1024"] = {"samples": S, "note": "the per-GPU share of the 8192-sample Monte-Carlo on an 8-GPU node", **res}
 if only in ("all", "coupled"):
-    # config 3 with non-ideal rails: ONE coupled block (sparse path: CSR assembly + level-scheduled LU refactor + solves)
+    # config 3 with non-ideal rails: ONE coupled block for the structural analysis.  Two solvers of the same Newton systems:
+    #   torn   — bordered block-diagonal form on the device-resident stepper: a register LU per tile and a Schur complement on the
+    #            two rail unknowns per Newton iteration (two grid-wide reductions), DC on the sparse path
+    #   sparse — CSR assembly + level-synchronous LU refactor + solves, one launch per level (CEDARHIP_NO_TEAR=1)
     for tiles in [int(x) for x in os.environ.get("CEDARHIP_COUPLED_TILES", "64,256,1024").split(",")]:
         c = dff_array(tiles, observe="q0", supply_r=1.0)
         e = EngineCircuit(c)
         opts = tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-12), saveat=np.array(DFF_CHECK_TIMES))
-        t0 = time.perf_counter()
-        rc, t, v, xf, st = e.tran(0.0, 7e-7, opts)
-        el = time.perf_counter() - t0
-        info = e.info()
-        nnz, nlu, n = info["nnz_jac"], info["nnz_lu"], info["n_unknowns"]
-        # algorithmic bytes per Newton iteration: eval 400 B + assembly 288 B per MOSFET + 8(nnz + n); LU 8(nnz + 2 nnz(L+U)); solves 8(2 nnz(L+U) + 4 n)
-        bpi = tiles * 30 * 688 + 8 * (nnz + n) + 8 * (nnz + 2 * nlu) + 8 * (2 * nlu + 4 * n)
-        q = [float(v[0, k, 0]) for k in range(len(DFF_CHECK_TIMES))] if rc == 0 else None
-        out["config3_coupled_%d_tiles" % tiles] = {"rc": rc, "path": info["path"], "unknowns": n, "blocks": info["n_components"], "nnz_jacobian": nnz, "nnz_lu": nlu,
-                                                    "wall_seconds": el, "accepted": st["naccept"], "rejected": st["nreject"], "newton_iters": st["nnonliniter"],
-                                                    "newton_iters_per_sec": st["nnonliniter"] / el, "launches": st["n_kernel_launches"],
-                                                    "algorithmic_bytes_per_iteration": bpi, "achieved_GBps_wall": bpi * st["nnonliniter"] / el / 1e9,
-                                                    "gate_q": q}
+        entry = {}
+        for label in ("torn", "sparse"):
+            if label == "sparse":
+                os.environ["CEDARHIP_NO_TEAR"] = "1"
+            else:
+                os.environ.pop("CEDARHIP_NO_TEAR", None)
+            e.tran(0.0, 7e-7, opts)   # warm-up: symbolic analysis, first-launch costs
+            t0 = time.perf_counter()
+            rc, t, v, xf, st = e.tran(0.0, 7e-7, opts)
+            el = time.perf_counter() - t0
+            info = e.info()
+            nnz, nlu, n = info["nnz_jac"], info["nnz_lu"], info["n_unknowns"]
+            # algorithmic bytes per Newton iteration: eval 400 B + assembly 288 B per MOSFET + 8(nnz + n); LU 8(nnz + 2 nnz(L+U)); solves 8(2 nnz(L+U) + 4 n)
+            bpi = tiles * 30 * 688 + 8 * (nnz + n) + 8 * (nnz + 2 * nlu) + 8 * (2 * nlu + 4 * n)
+            tran_s = el - st["dc_seconds"]
+            tran_iters = st["step_block_iters"] / tiles if label == "torn" else st["nnonliniter"]
+            entry[label] = {"rc": rc, "stepper": st["stepper"], "wall_seconds": el, "dc_seconds": st["dc_seconds"], "transient_seconds": tran_s,
+                            "accepted": st["naccept"], "rejected": st["nreject"], "newton_iters": st["nnonliniter"], "step_attempts": st["n_step_attempts"],
+                            "newton_iters_per_sec": st["nnonliniter"] / el, "us_per_attempt_transient": 1e6 * tran_s / max(1, st["n_step_attempts"]),
+                            "launches": st["n_kernel_launches"], "achieved_GBps_wall": bpi * st["nnonliniter"] / el / 1e9,
+                            "gate_q": [float(v[0, k, 0]) for k in range(len(DFF_CHECK_TIMES))] if rc == 0 else None}
+        os.environ.pop("CEDARHIP_NO_TEAR", None)
+        out["config3_coupled_%d_tiles" % tiles] = {"path": info["path"], "unknowns": n, "blocks": info["n_components"], "nnz_jacobian": nnz, "nnz_lu": nlu,
+                                                    "algorithmic_bytes_per_iteration": bpi, **entry}
 if only in ("all", "config5"):
     cards = json.load(open(os.path.join(ROOT, "cedarsim.jl_amd", "data", "asap7_tt_lvt_cards.json")))["cards"]
     c = cmg_inverter_array(128, cards)
