@@ -253,6 +253,7 @@ struct ch_circuit {
   std::unique_ptr<ch_circuit> torn_c;
   bool is_torn = false;
   std::string torn_note;
+  std::vector<int> dsrc_host;               // per flattened device: source slot (or Verilog-A parameter offset), as uploaded
   std::vector<double> h_dpar0, h_dmult0;   // main parameter and multiplicity of every device as uploaded (sample 0)
   SparsePlan plan[2];           // [0] DC (alpha0 = 0), [1] transient
   struct PlanDev { DevBuf<int> prow, pcol, a2lu, diag_pos, lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows, lrow_ptr, l_pos, l_k, l_upd_ptr, upd_dst, upd_src, urow_ptr, u_pos, u_col;
@@ -351,7 +352,8 @@ struct ch_circuit {
     block_threads = std::min(256, std::max(64, ((max_slots + 63) / 64) * 64));
     lu_variant = A.max_nc <= 8 ? 8 : (A.max_nc <= 12 ? 12 : (A.max_nc <= 16 ? 16 : (A.max_nc <= 32 ? 32 : 0)));
     if (A.wide) lu_variant = A.max_nc <= 16 ? 16 : 0;  // wide (Verilog-A) stamp records: two instantiations only
-    std::vector<int> dkind, dterm, dsrc, dhdev;
+    std::vector<int> dkind, dterm, dhdev;
+    std::vector<int>& dsrc = dsrc_host; dsrc.clear();
     dev_src.clear();
     { std::vector<int> slot_of(src.size(), -1);
       for (const EDev& e : A.edev) {
@@ -1082,7 +1084,7 @@ struct ch_circuit {
 
   // ------------------------------------------------------------------------------------------
   // Device-resident step controller: which circuits qualify (ch_persist.hpp header), and the launch.
-  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl;
+  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pkmap, d_psmap;
   int n_cu = 0;
   // `own_steps`: the batch would run with per-sample step acceptance (no grid-wide wait anywhere in the kernel), so the workgroups
   // need not be co-resident and any number of samples can be queued behind each other
@@ -1094,7 +1096,8 @@ struct ch_circuit {
     if (!(lu_variant == 8 || lu_variant == 12 || lu_variant == 16)) return no("a Jacobian block has more than 16 unknowns");
     if (block_threads != 64 || max_mc > 8) return no("a block needs more than one wavefront of device slots or more than 8 MOSFET classes");
     if (Ssrc != 1) return no("per-sample source parameters");
-    if (needed_src.size() > (size_t)P_MAXSRC || A.known.size() + (size_t)n_dev_src() > 64) return no("more than 64 sources / known-node and source values per attempt");
+    const bool wg_consts = own_steps && S == 1 && A.n_comp > 1;   // per-block steps: every workgroup gets the sources of ITS blocks only (checked there)
+    if (!wg_consts && (needed_src.size() > (size_t)P_MAXSRC || A.known.size() + (size_t)n_dev_src() > 64)) return no("more than 64 sources / known-node and source values per attempt");
     if (!(S == 1 || A.n_comp == 1)) return no("several blocks per sample in a multi-sample batch");
     if (A.nb > 0 && (S != 1 || A.border_dev.size() > 8)) return no("bordered form: one sample and at most 8 devices on the border alone");
     for (const ClassMeta& m : h_cms) if (m.nslots > 64 || m.nc > lu_variant || m.n_work <= 0) return no("a block class does not fit the one-wave register path");
@@ -1102,14 +1105,18 @@ struct ch_circuit {
     const long nblk = (long)A.n_comp * S;
     if (nblk > (long)PW * n_cu && !own_steps) return no("more blocks than resident wavefronts (4 per CU)");
     size_t npwl = 0; for (int i : needed_src) npwl += src[i].ts.size();
-    if (npwl > 2048) return no("piecewise-linear tables above 2048 points");
+    if (!wg_consts && npwl > 2048) return no("piecewise-linear tables above 2048 points");
     return true;
   }
+  // Every sample of a batch (n_comp == 1) or every block of one circuit of independent blocks (S == 1) takes its own steps when
+  // the output is wanted on a common `saveat` grid: independent blocks ARE independent problems, a shared step size only makes
+  // each pay for the others' break points and dilutes its local error in the array-wide norm.  (Not for the bordered form.)
   bool persist_own_steps(const ch_tran_opts& o) const {
-    return A.n_comp == 1 && S > 1 && o.n_saveat > 0 && std::getenv("CEDARHIP_LOCKSTEP") == nullptr;
+    return ((A.n_comp == 1 && S > 1) || (S == 1 && A.n_comp > 1 && A.nb == 0)) && o.n_saveat > 0 && std::getenv("CEDARHIP_LOCKSTEP") == nullptr;
   }
-  size_t persist_wave_doubles() const {
-    return lds_doubles_fixed + 16 * (size_t)A.max_nc + 10 + 48 + P_MAXSRC + A.known.size() + n_dev_src() + (size_t)max_mc * B4L_STRIDE + (lds_extra_bytes + 7) / 8 + 2;
+  size_t persist_wave_doubles(bool wg_consts) const {
+    const size_t n_ent = wg_consts ? (size_t)P_MAXSRC : A.known.size() + n_dev_src();
+    return lds_doubles_fixed + 16 * (size_t)A.max_nc + 10 + 48 + P_MAXSRC + n_ent + (size_t)max_mc * B4L_STRIDE + (lds_extra_bytes + 7) / 8 + 2;
   }
   int tran_persistent(double t0, double t1, const ch_tran_opts& o, ch_result& R, const std::vector<double>& bps, int kmax, double dtmin, double dtmax,
                       int max_steps, int nmaxit, hclock::time_point tstart, bool& used) {
@@ -1119,26 +1126,71 @@ struct ch_circuit {
     const int n_obs = R.n_obs;
     const int nblk = A.n_comp * S, n_wg = (nblk + PW - 1) / PW;
     // ---- constants blob: needed sources, known-node definitions, device-source map, PWL tables ----
+    // One blob for the whole grid, or — per-block steps of one circuit (wg_consts) — one per workgroup holding only what its
+    // blocks reference, with a map from the circuit's known-node / device-source indices to the workgroup's entries: a block with
+    // its own clock source neither evaluates nor stops at the other 1023 clocks.
+    const bool own_steps = persist_own_steps(o);
+    const bool wg_consts = own_steps && S == 1 && A.n_comp > 1;
     std::vector<int> ci; std::vector<double> cd;
-    {
-      const int nsrc = (int)src.size(), nk = (int)A.known.size(), nds = n_dev_src();
+    const int nsrc = (int)src.size(), nk = (int)A.known.size(), nds = n_dev_src();
+    // entries `kn` (known-node indices) then `ds` (device-source slots) -> blob; false when a limit of the kernel is exceeded
+    auto build_blob = [&](const std::vector<int>& kn, const std::vector<int>& ds, std::vector<int>& bi, std::vector<double>& bd, std::vector<int>& need) -> bool {
+      std::vector<char> nd(std::max(1, nsrc), 0);
+      for (int k : kn) for (auto& tm : A.known[k].terms) nd[tm.first] = 1;
+      for (int j : ds) if (j < (int)dev_src.size()) nd[dev_src[j]] = 1;
+      need.clear();
+      for (int i = 0; i < nsrc; ++i) if (nd[i]) need.push_back(i);
       std::vector<int> pos(std::max(1, nsrc), -1);
-      for (size_t i = 0; i < needed_src.size(); ++i) pos[needed_src[i]] = (int)i;
+      for (size_t i = 0; i < need.size(); ++i) pos[need[i]] = (int)i;
       std::vector<double> pt, py;
-      ci = {(int)needed_src.size(), nk + nds, 0, 0};
-      for (int i : needed_src) { ci.push_back(src[i].kind); ci.push_back((int)pt.size()); ci.push_back((int)src[i].ts.size()); pt.insert(pt.end(), src[i].ts.begin(), src[i].ts.end()); py.insert(py.end(), src[i].ys.begin(), src[i].ys.end()); }
-      ci[2] = (int)pt.size();
-      // entries: the nk known-node values, then the nds device source values (kvl and svl are contiguous in LDS)
+      bi = {(int)need.size(), (int)(kn.size() + ds.size()), 0, (int)kn.size()};
+      for (int i : need) { bi.push_back(src[i].kind); bi.push_back((int)pt.size()); bi.push_back((int)src[i].ts.size()); pt.insert(pt.end(), src[i].ts.begin(), src[i].ts.end()); py.insert(py.end(), src[i].ys.begin(), src[i].ys.end()); }
+      bi[2] = (int)pt.size();
+      // entries: the known-node values, then the device source values (kvl and svl are contiguous in LDS)
       std::vector<int> eptr(1, 0), eidx; std::vector<double> ecoef;
-      for (int k = 0; k < nk; ++k) { for (auto& tm : A.known[k].terms) { eidx.push_back(pos[tm.first]); ecoef.push_back(tm.second); } eptr.push_back((int)eidx.size()); }
-      for (int j = 0; j < nds; ++j) { if (j < (int)dev_src.size()) { eidx.push_back(pos[dev_src[j]]); ecoef.push_back(1.0); } eptr.push_back((int)eidx.size()); }
-      ci.insert(ci.end(), eptr.begin(), eptr.end()); ci.insert(ci.end(), eidx.begin(), eidx.end());
-      for (int i : needed_src) for (int k = 0; k < CH_SRC_NPAR; ++k) cd.push_back(h_src_par[(size_t)i * CH_SRC_NPAR + k]);
-      cd.insert(cd.end(), ecoef.begin(), ecoef.end()); cd.insert(cd.end(), pt.begin(), pt.end()); cd.insert(cd.end(), py.begin(), py.end());
-      for (int v : ci) if (v < 0) { set_err("internal: a needed source is missing from the evaluation list"); return CH_ERR_INTERNAL; }
+      for (int k : kn) { for (auto& tm : A.known[k].terms) { eidx.push_back(pos[tm.first]); ecoef.push_back(tm.second); } eptr.push_back((int)eidx.size()); }
+      for (int j : ds) { if (j < (int)dev_src.size()) { eidx.push_back(pos[dev_src[j]]); ecoef.push_back(1.0); } eptr.push_back((int)eidx.size()); }
+      bi.insert(bi.end(), eptr.begin(), eptr.end()); bi.insert(bi.end(), eidx.begin(), eidx.end());
+      bd.clear();
+      for (int i : need) for (int k = 0; k < CH_SRC_NPAR; ++k) bd.push_back(h_src_par[(size_t)i * CH_SRC_NPAR + k]);
+      bd.insert(bd.end(), ecoef.begin(), ecoef.end()); bd.insert(bd.end(), pt.begin(), pt.end()); bd.insert(bd.end(), py.begin(), py.end());
+      for (size_t q = 4; q < bi.size(); ++q) if (bi[q] < 0) return false;
+      return need.size() <= (size_t)P_MAXSRC && kn.size() + ds.size() <= 64 && pt.size() <= 2048;
+    };
+    std::vector<int> wgc, kmap, smap;          // wg_consts: per workgroup {ci offset, cd offset, n_ci, n_cd, bps offset, nbp}; index maps
+    std::vector<double> bps_all;
+    size_t max_ci = 0, max_cd = 0;
+    if (!wg_consts) {
+      std::vector<int> kn(nk), ds(nds), need;
+      std::iota(kn.begin(), kn.end(), 0); std::iota(ds.begin(), ds.end(), 0);
+      if (!build_blob(kn, ds, ci, cd, need)) { set_err("device-resident stepper: the source tables exceed the kernel's limits"); return CH_OK; }
+      max_ci = ci.size(); max_cd = cd.size();
+    } else {
+      kmap.assign((size_t)n_wg * nk, 0); smap.assign((size_t)n_wg * nds, 0);
+      for (int w = 0; w < n_wg; ++w) {
+        std::vector<char> uk(nk, 0), ud(nds, 0);
+        for (int b = w * PW; b < std::min(nblk, (w + 1) * PW); ++b)
+          for (int i = 0; i < A.comp_ndev[b]; ++i) {
+            const EDev& e = A.edev[A.comp_dofs[b] + i];
+            for (int k = 0; k < NTERM; ++k) if (e.term[k] < 0) uk[-e.term[k] - 1] = 1;
+            if (e.src >= 0) ud[dsrc_host[A.comp_dofs[b] + i]] = 1;
+          }
+        std::vector<int> kn, ds, need, bi; std::vector<double> bd;
+        for (int k = 0; k < nk; ++k) if (uk[k]) { kmap[(size_t)w * nk + k] = (int)kn.size(); kn.push_back(k); }
+        for (int j = 0; j < nds; ++j) if (ud[j]) { smap[(size_t)w * nds + j] = (int)ds.size(); ds.push_back(j); }
+        if (ds.empty()) ds.push_back(0);   // the kernel's source-value array is never empty
+        if (!build_blob(kn, ds, bi, bd, need)) { set_err("device-resident stepper: a workgroup's blocks reference more than 64 sources / known nodes"); return CH_OK; }
+        std::vector<double> wb;
+        for (int i : need) source_breakpoints(src[i], &h_src_par[(size_t)i * CH_SRC_NPAR], t0, t1, wb);
+        wb.push_back(t1);
+        std::sort(wb.begin(), wb.end()); wb.erase(std::unique(wb.begin(), wb.end()), wb.end());
+        wgc.insert(wgc.end(), {(int)ci.size(), (int)cd.size(), (int)bi.size(), (int)bd.size(), (int)bps_all.size(), (int)wb.size()});
+        ci.insert(ci.end(), bi.begin(), bi.end()); cd.insert(cd.end(), bd.begin(), bd.end()); bps_all.insert(bps_all.end(), wb.begin(), wb.end());
+        max_ci = std::max(max_ci, bi.size()); max_cd = std::max(max_cd, bd.size());
+      }
     }
-    const size_t wave_d = persist_wave_doubles();
-    const size_t lds = (cd.size() + (ci.size() + 1) / 2 + PW * P_NREC + P_NREC + 4 + PW * wave_d) * sizeof(double);
+    const size_t wave_d = persist_wave_doubles(wg_consts);
+    const size_t lds = (max_cd + (max_ci + 1) / 2 + PW * P_NREC + P_NREC + 4 + PW * wave_d) * sizeof(double);
     // wave pairs share the device evaluation by function when every block has the same class and at most 32 evaluation slots
     const bool pair = A.classes.size() == 1 && h_cms[0].nslots <= 32 && std::getenv("CEDARHIP_PERSIST_NOPAIR") == nullptr;
     if (lds > 150 * 1024) { set_err("device-resident stepper: the workgroup's LDS footprint exceeds 150 KB"); return CH_OK; }
@@ -1148,22 +1200,24 @@ struct ch_circuit {
     if (o.n_saveat > 0) max_rows = (long long)o.n_saveat + 1;
     else max_rows = std::min<long long>((long long)max_steps + 2, std::max<long long>(1024, std::min<long long>(1 << 20, (long long)((256u << 20) / (row_d * sizeof(double))))));
     if (o.n_saveat == 0 && std::getenv("CEDARHIP_PERSIST_MAXROWS")) max_rows = std::max(2L, std::atol(std::getenv("CEDARHIP_PERSIST_MAXROWS")));   // test hook: forces the drain-and-resume path
-    HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(bps, st));
+    HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(wg_consts ? bps_all : bps, st));
+    if (wg_consts) { HIPCHK(d_pwgc.upload(wgc, st)); HIPCHK(d_pkmap.upload(kmap, st)); HIPCHK(d_psmap.upload(smap, st)); }
     { std::vector<double> sv(o.saveat, o.saveat + std::max(0, o.n_saveat)); if (sv.empty()) sv.push_back(0.0); HIPCHK(d_psave.upload(sv, st)); }
     HIPCHK(d_ptimes.alloc((size_t)max_rows)); HIPCHK(d_prows.alloc((size_t)max_rows * row_d));
     HIPCHK(d_wgrec.alloc((size_t)2 * n_wg * 16)); HIPCHK(d_grprec.alloc(2 * 8 * 16)); /* 16 granules per record, double-buffered by generation parity */ HIPCHK(d_pcnt.alloc(10 * 32)); HIPCHK(d_pctl.alloc(2));   /* controller state in; [1]: exit state of a batch with per-sample steps */
     PersistArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.a = base;
     pa.a.mode = MODE_TRAN; pa.a.maxit = nmaxit; pa.a.abstol = o.abstol; pa.a.reltol = o.reltol; pa.a.newton_tol = 0.1; pa.a.active = nullptr; pa.a.gshunt = 0.0;
-    pa.nblk = nblk; pa.n_wg = n_wg; pa.red_max = (S > 1) ? 1 : 0; pa.wave_doubles = (int)wave_d;
+    pa.nblk = nblk; pa.n_wg = n_wg; pa.red_max = (S > 1 || own_steps) ? 1 : 0; pa.wave_doubles = (int)wave_d;
     pa.t1 = t1; pa.dtmin = dtmin; pa.dtmax = dtmax; pa.first_frac = 1e-3; pa.kmax = kmax; pa.max_steps = max_steps;
     pa.bps = d_pbps.p; pa.nbp = (int)bps.size(); pa.saveat = d_psave.p; pa.n_saveat = o.n_saveat;
-    pa.ci = d_pci.p; pa.cd = d_pcd.p; pa.n_ci = (int)ci.size(); pa.n_cd = (int)cd.size();
+    pa.ci = d_pci.p; pa.cd = d_pcd.p; pa.n_ci = (int)max_ci; pa.n_cd = (int)max_cd;   // layout sizes (the largest workgroup blob)
+    pa.wgc = wg_consts ? d_pwgc.p : nullptr; pa.kmap = wg_consts ? d_pkmap.p : nullptr; pa.smap = wg_consts ? d_psmap.p : nullptr; pa.n_kmap = nk; pa.n_smap = nds;
     pa.out_times = d_ptimes.p; pa.out_rows = d_prows.p; pa.max_rows = max_rows; pa.n_obs = n_obs;
     pa.ctl = d_pctl.p; pa.wg_rec = d_wgrec.p; pa.grp_rec = d_grprec.p; pa.counters = d_pcnt.p;
     pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz
     // a batch of single-block samples on a common output grid: every sample its own step sequence (no lock-step, no grid reduction)
-    pa.indep = persist_own_steps(o) ? 1 : 0;
+    pa.indep = own_steps ? 1 : 0;
     pa.nb = A.nb; pa.n_glob = A.n_glob; pa.n_bdev = (int)A.border_dev.size();
     for (int q = 0; q < pa.n_bdev; ++q) {
       const Analysis::BorderDev& bd = A.border_dev[q];
@@ -1178,7 +1232,10 @@ struct ch_circuit {
     double h = o.dt0 > 0 ? o.dt0 : std::min(dtmax, 1e-3 * span);
     h = std::max(10 * dtmin, std::min(h, (bps[0] - t0) / 50.0) * 1e-3);
     cs.t = t0; cs.h = h; cs.k = 1; cs.nhist = 1; cs.reset_rate = 1; cs.tslot[0] = t0;
-    const void* fn = lu_variant <= 12 ? (pair ? (const void*)tran_persistent_kernel<12, true> : (const void*)tran_persistent_kernel<12, false>)
+    const void* fn = A.nb > 0 ? (pair ? (const void*)tran_persistent_kernel<16, true, PM_BORDER> : (const void*)tran_persistent_kernel<16, false, PM_BORDER>)
+                   : own_steps ? (lu_variant <= 12 ? (pair ? (const void*)tran_persistent_kernel<12, true, PM_OWN> : (const void*)tran_persistent_kernel<12, false, PM_OWN>)
+                                                   : (pair ? (const void*)tran_persistent_kernel<16, true, PM_OWN> : (const void*)tran_persistent_kernel<16, false, PM_OWN>))
+                   : lu_variant <= 12 ? (pair ? (const void*)tran_persistent_kernel<12, true> : (const void*)tran_persistent_kernel<12, false>)
                                       : (pair ? (const void*)tran_persistent_kernel<16, true> : (const void*)tran_persistent_kernel<16, false>);
     {
       hipFuncAttributes fa;
@@ -1231,8 +1288,9 @@ struct ch_circuit {
       std::fprintf(stderr, "\n"); }
 #endif
     R.stats.naccept += cs.naccept; R.stats.nreject += cs.nreject; R.stats.nnonlinconvfail += cs.nconvfail;
-    R.stats.n_block_iters += cs.sum_block_iters; R.stats.nnonliniter += cs.sum_iters; R.stats.nf += cs.sum_iters; R.stats.njacs += cs.sum_iters;
-    R.stats.nfactors += cs.sum_iters; R.stats.nsolve += cs.sum_iters;
+    const long long arr_iters = (own_steps && S == 1) ? cs.max_iters : cs.sum_iters;   // one circuit: Newton iterations of its slowest block
+    R.stats.n_block_iters += cs.sum_block_iters; R.stats.nnonliniter += arr_iters; R.stats.nf += arr_iters; R.stats.njacs += arr_iters;
+    R.stats.nfactors += arr_iters; R.stats.nsolve += arr_iters;
     const size_t nt = htimes.size();
     R.times = htimes;
     R.values.assign((size_t)n_obs * nt * S, 0.0);

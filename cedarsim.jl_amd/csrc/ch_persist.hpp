@@ -40,6 +40,7 @@ struct TranCtl {
   int ibp, isave, status, exit_reason;
   long long nsaved, step;
   long long naccept, nreject, nconvfail, sum_iters, sum_block_iters, n_attempts;
+  long long max_iters;                          // per-block / per-sample steps: Newton iterations of the slowest block
   long long t_cycles_total, t_cycles_barrier;   // wave 0 of workgroup 0: cycles inside the kernel / inside the grid reductions
   long long stamps[12];                         // diagnostic build (-DCH_STAMPS): shader-clock cycles per phase, wave 0 of workgroup 0
 };
@@ -52,6 +53,10 @@ struct PersistArgs {
   int kmax, max_steps, nbp, n_saveat;
   const double* bps; const double* saveat;
   const int* ci; const double* cd; int n_ci, n_cd;   // constants blob (sources, known-node definitions), copied to LDS
+  // per-block steps of ONE circuit: a blob per workgroup with the sources of its own blocks only.  wgc[6 wg ..] = {ci offset,
+  // cd offset, n_ci, n_cd, break-point offset, break-point count}; n_ci / n_cd above are then the largest sizes (LDS layout);
+  // kmap[wg][known index] / smap[wg][device-source slot] -> the workgroup's entry numbers
+  const int* wgc; const int* kmap; const int* smap; int n_kmap, n_smap;
   double* out_times; double* out_rows; long long max_rows; int n_obs;
   TranCtl* ctl; int resume;
   double* wg_rec; double* grp_rec; unsigned* counters;   // grid reduction: [n_wg][8], [8][8], 10 counters on 128-byte lines
@@ -215,10 +220,11 @@ __device__ __forceinline__ p_u64 p_split(double v, int lane, unsigned gen) {
   const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
   return ((p_u64)gen << 32) | half;
 }
+template <bool ALL_SUM = false>   // ALL_SUM: every field combined with + (the Schur-complement and norm records of the bordered form)
 __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const double* rec /* 8 wave-uniform values */, double* part, double* summ,
-                                     int* s_abort, int wave, int lane, int wg, bool all_sum = false) {
+                                     int* s_abort, int wave, int lane, int wg) {
   const int g16 = lane & 15, f = g16 >> 1, m4 = lane >> 4;   // granule of the record, its field, member slot of a sweep
-  const bool fmaxop = !all_sum && ((f == 4) || (p.red_max && f < 3));
+  const bool fmaxop = !ALL_SUM && ((f == 4) || (p.red_max && f < 3));
   if (lane < P_NREC) {
     double v = rec[0];
 #pragma unroll
@@ -345,7 +351,12 @@ __device__ __forceinline__ double p_coef(double tau0, const double* tsl, int hea
 // attempt — shrinks to its longer half, with one wave per SIMD as before.  The pair meets twice per Newton iteration through
 // two counters in LDS (in-order LDS pipeline: a wave's stamp writes precede its counter write).  Requires one block class and
 // at most 32 evaluation slots per block.
-template <int NC, bool PAIR>
+// MODE: 0 = one step sequence for the whole grid (grid-wide reduction per attempt); 1 = every sample / block its own steps
+// (PersistArgs::indep, optionally per-workgroup constants); 2 = the bordered block-diagonal form (PersistArgs::nb > 0).  Separate
+// instantiations, so that the lock-step kernel of the headline workload carries none of the others' state (the shared-code
+// versions cost the 1024-DFF array 3 - 8 %).
+enum { PM_LOCKSTEP = 0, PM_OWN = 1, PM_BORDER = 2 };
+template <int NC, bool PAIR, int MODE = PM_LOCKSTEP>
 __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const PersistArgs p) {
   typedef StampLayout<false> SL;
   extern __shared__ double lds[];
@@ -364,8 +375,21 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   double* summ = part + PW * P_NREC;
   int* pfl = (int*)(summ + P_NREC);   // per pair: {sequence of wave 2q, of wave 2q+1, done flag of block 2q, of block 2q+1}
   double* W = summ + P_NREC + 4 + (size_t)wave * p.wave_doubles;
-  for (int i = tid; i < p.n_cd; i += PW * 64) cdl[i] = p.cd[i];
-  for (int i = tid; i < p.n_ci; i += PW * 64) cil[i] = p.ci[i];
+  constexpr bool own = MODE == PM_OWN;
+  const int* const wgc = own ? p.wgc : nullptr;
+  const double* bps_own = nullptr; int nbp_own = 0;   // per-workgroup break points (the other modes read p.bps / p.nbp where they need them)
+  if (own && wgc) {
+    const int* e = wgc + 6 * wg;
+    const int* gci = p.ci + e[0]; const double* gcd = p.cd + e[1]; const int n_ci = e[2], n_cd = e[3];
+    bps_own = p.bps + e[4]; nbp_own = e[5];
+    for (int i = tid; i < n_cd; i += PW * 64) cdl[i] = gcd[i];
+    for (int i = tid; i < n_ci; i += PW * 64) cil[i] = gci[i];
+  } else {
+    for (int i = tid; i < p.n_cd; i += PW * 64) cdl[i] = p.cd[i];
+    for (int i = tid; i < p.n_ci; i += PW * 64) cil[i] = p.ci[i];
+  }
+#define P_BPS ((own && wgc) ? bps_own : p.bps)
+#define P_NBP ((own && wgc) ? nbp_own : p.nbp)
   if (tid == 0) s_abort = 0;
   if (tid < 8) pfl[tid] = 0;
   __syncthreads();
@@ -388,8 +412,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   double* Xh = x0l + 2 * nc; double* Qh = Xh + 8 * nc;
   double* tsl = Qh + 8 * nc; double* coef = tsl + 8;
   long long* stl = (long long*)(coef + 40);   // statistics counters (lane 0 updates them): they would only crowd the scalar registers
-  double* kvl = coef + 48; double* svl = kvl + a.nk;
-  double* pl = svl + a.nsrc;
+  double* kvl = coef + 48; double* svl = kvl + (wgc ? C.ci[3] : a.nk);     // a workgroup blob numbers its own entries
+  double* pl = wgc ? kvl + P_MAXSRC : svl + a.nsrc;
   int* mptr = (int*)(pl + (size_t)a.max_mc * B4L_STRIDE);
   int* slots = mptr + (nc * nc + 1) + (nc + 1);
   uint16_t* msrc = (uint16_t*)(slots + cm.nslots);
@@ -473,6 +497,12 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     if (PAIR) { const int sq = lane & 31; if (live_h && sq < cm.nslots) slot = slots_h[sq]; }
     else if (live && lane < cm.nslots) slot = slots[lane];
     smeta = load_slot_meta(ectx, PAIR ? s_h : s, PAIR ? dofs_h : dofs, PAIR ? uofs_h : uofs, slot);
+    if (wgc && smeta.kind != 0) {   // known nodes and device sources by the workgroup's own entry numbers
+      const int* km = p.kmap + (size_t)wg * p.n_kmap; const int* sm = p.smap + (size_t)wg * p.n_smap;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (smeta.t[k] < 0) smeta.t[k] = -(km[-smeta.t[k] - 1] + 1);
+      if (smeta.kind == K_I || smeta.kind == K_V) smeta.src = sm[smeta.src];
+    }
   }
   const int n_ent = C.n_ent();
   // this lane's entry (a known-node or device-source value): its terms, and the linear piece of up to two of them
@@ -511,8 +541,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     asm volatile("" : "+v"(ln));
     // next break point: global loads only when the index moves
     for (;;) {
-      if (bp_at != ibp) { bp_next = ibp < p.nbp ? p.bps[ibp] : p.t1; bp_at = ibp; }
-      if (ibp < p.nbp && bp_next <= t * (1 + 1e-15) + 1e-300) ++ibp; else break;
+      if (bp_at != ibp) { bp_next = ibp < P_NBP ? P_BPS[ibp] : p.t1; bp_at = ibp; }
+      if (ibp < P_NBP && bp_next <= t * (1 + 1e-15) + 1e-300) ++ibp; else break;
     }
     const double tb = bp_next;
     bool hit_bp = false;
@@ -579,7 +609,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     double rate_new = -1.0, dn_prev = 0.0;
     const double rp = reset_rate ? 1.0 : rate_prev;
     bool done_own = !live;
-    const bool bbd = p.nb > 0;
+    constexpr bool bbd = MODE == PM_BORDER;
     const int no = nc - p.nb;                            // the block's own unknowns; lanes no .. nc-1 hold its border replicas
     bool stop_all = false, abort_all = false;            // bordered form: grid-uniform decisions
     double bA = 0.0, bB = 0.0, bC = 0.0, bN = 0.0;       // bordered form: the local-error sums of the last iteration's reduction
@@ -602,11 +632,11 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
             if (done_own) continue;
           }
         } else {
-        if (live) eval_cached<-1>(smeta, gmin_h, xl, kvl, svl, pl, st);
+        if (!bbd || live) eval_cached<-1>(smeta, gmin_h, xl, kvl, svl, pl, st);
         lds_fence();
         P_STAMP(4);   // device evaluation
         }
-        for (int w = lane; w < (live ? cm.n_work : 0); w += 64) {
+        for (int w = lane; w < ((bbd && !live) ? 0 : cm.n_work); w += 64) {
           const int2 itw = wl[w];
           const int p0 = itw.x, pe = p0 + (int)((unsigned)itw.y >> 16), e = itw.y & 0x7fff;
           const bool vec = itw.y & 0x8000;
@@ -660,7 +690,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
           }
           ++gen;
           const long long cbA = wall_clock64();
-          bool okr = p_grid_reduce(p, gen, srec, part, summ, &s_abort, wave, lane, wg, true);
+          bool okr = p_grid_reduce<true>(p, gen, srec, part, summ, &s_abort, wave, lane, wg);
           double S00 = summ[0], S01 = summ[1], g0 = summ[2], S10 = summ[3], S11 = summ[4], g1 = summ[5];
           const bool gfail = summ[6] != 0.0;
           if (!okr || summ[7] != 0.0) abort_all = true;
@@ -732,7 +762,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
           double brec[P_NREC] = {l2k, l2m, l2p, lnd, e2own, lbad, 0.0, pair_broken ? 1.0 : 0.0};
           ++gen;
           const long long cbB = wall_clock64();
-          okr = p_grid_reduce(p, gen, brec, part, summ, &s_abort, wave, lane, wg, true);
+          okr = p_grid_reduce<true>(p, gen, brec, part, summ, &s_abort, wave, lane, wg);
           bA = summ[0]; bB = summ[1]; bC = summ[2]; bN = summ[3];
           const double e2g = summ[4]; const bool gbad = summ[5] != 0.0;
           if (!okr || summ[7] != 0.0) abort_all = true;
@@ -808,7 +838,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     P_STAMP(9);   // candidate, local-error sums
     const long long cb0 = wall_clock64();
     double sA, sB, sC, sN, sItMax, sItSum, sFail;
-    if (p.indep) {
+    if (own) {
       // per-sample step acceptance: the record is combined over the wave pair only (the two samples that share a device
       // evaluation stay in lock-step), or not at all
       double r8[P_NREC];
@@ -919,7 +949,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     if (hit_bp && t < p.t1) {
       nhist = 1; k = 1; steps_at_order = 0; reset_rate = true;
       double nb = p.t1;
-      for (int b = ibp; b < p.nbp; ++b) if (p.bps[b] > t * (1 + 1e-15)) { nb = p.bps[b]; break; }
+      for (int b = ibp; b < P_NBP; ++b) if (P_BPS[b] > t * (1 + 1e-15)) { nb = P_BPS[b]; break; }
       h = fmax(p.dtmin * 10, fmin(h, (nb - t) / 50.0) * p.first_frac);
     }
     P_STAMP(11);  // controller, saved rows
@@ -937,7 +967,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       a.Qh[(long)j * a.slot_stride + sofs + lane] = Qh[sl * nc + lane];
     }
   }
-  if (p.indep) {
+  if (own) {
     // every sample reports for itself: sums of iterations, the longest chain of attempts, the worst status
     // (into the second record: workgroups queued behind this one still read their initial state from the first)
     if (live && lane == 0) {
@@ -945,7 +975,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       typedef unsigned long long u64;
       atomicAdd((u64*)&cs->sum_iters, (u64)stl[ST_ITERS]); atomicAdd((u64*)&cs->sum_block_iters, (u64)stl[ST_BITERS]);
       atomicMax((u64*)&cs->naccept, (u64)stl[ST_ACC]); atomicMax((u64*)&cs->nreject, (u64)stl[ST_REJ]); atomicMax((u64*)&cs->nconvfail, (u64)stl[ST_FAIL]);
-      atomicMax((u64*)&cs->n_attempts, (u64)stl[ST_ATT]); atomicMax((u64*)&cs->nsaved, (u64)nsaved);
+      atomicMax((u64*)&cs->n_attempts, (u64)stl[ST_ATT]); atomicMax((u64*)&cs->nsaved, (u64)nsaved); atomicMax((u64*)&cs->max_iters, (u64)stl[ST_ITERS]);
       atomicMin(&cs->status, status); atomicMax(&cs->exit_reason, exit_reason);
       if (blk == 0) { cs->t = t; cs->h = h; cs->isave = isave; cs->t_cycles_total = wall_clock64() - cyc0; cs->t_cycles_barrier = cyc_bar; }
     }
@@ -962,5 +992,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
 #endif
   }
 }
+
+#undef P_BPS
+#undef P_NBP
 
 }  // namespace chip

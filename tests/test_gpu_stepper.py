@@ -131,6 +131,37 @@ def test_more_samples_than_resident_wavefronts_queue_on_the_device_stepper(E):
     assert np.max(np.abs(vh - vd)) < 1e-5
 
 
+def test_blocks_of_one_circuit_take_their_own_steps_on_a_saveat_grid(E):
+    """Independent blocks of ONE circuit on a common output grid are stepped block by block (no grid-wide reduction, every
+    workgroup evaluates and stops at the sources of its own blocks only): the DFF array with per-tile clock skew (a private clock
+    source per tile) against the lock-step controller at a tight tolerance, where both must land on the same waveforms."""
+    rng = np.random.default_rng(1234)
+    tiles = 24
+    e = E(dff_array(tiles, skew=rng.uniform(0.0, 50e-12, tiles), observe="q"))
+    sv = np.linspace(0.0, 7e-7, 141)
+    kw = dict(abstol=1e-7, reltol=1e-7, saveat=sv, dc=dc_opts(abstol=1e-14))
+    t1, v1, x1, st1 = run(e, DFF_TSPAN, "device", **kw)
+    os.environ["CEDARHIP_LOCKSTEP"] = "1"
+    try:
+        t2, v2, x2, st2 = run(e, DFF_TSPAN, "auto", **kw)
+    finally:
+        del os.environ["CEDARHIP_LOCKSTEP"]
+    assert st1["stepper"] == 2 and v1.shape == (tiles, 141, 1)
+    assert np.max(np.abs(v1 - v2)) < 1e-5, np.max(np.abs(v1 - v2))
+    assert st1["n_step_attempts"] < 0.8 * st2["n_step_attempts"]          # no block pays for the others' clock corners
+    assert st1["n_block_iters"] < 0.8 * st2["n_block_iters"]
+    ok = ~np.isnan(x2[0])
+    assert np.allclose(x1[0][ok], x2[0][ok], rtol=0, atol=1e-5)
+    q = np.array([[np.interp(tt, t1, v1[k, :, 0]) for tt in DFF_CHECK_TIMES] for k in range(tiles)])
+    assert np.max(np.abs(q - np.array(DFF_CHECK_Q)[None, :])) < 1e-3
+    # identical tiles stepped block by block: the same answer in every tile, and the single flip-flop's
+    e3 = E(dff_array(6, observe="q"))
+    t3, v3, _, st3 = run(e3, DFF_TSPAN, "device", **kw)
+    e4 = E(dff_array(1, observe="q0"))
+    t4, v4, _, st4 = run(e4, DFF_TSPAN, "device", **kw)
+    assert np.max(np.abs(v3 - v3[0:1])) < 1e-9 and np.max(np.abs(v3[0] - v4[0])) < 1e-6
+
+
 def test_row_buffer_drain_and_resume(E):
     """Without saveat every accepted step is a row; when the device row buffer fills, the kernel stops with its controller state
     and history written back and the host relaunches it (resume): the result must not depend on where the cuts fall."""
