@@ -14,10 +14,28 @@ import numpy as np  # noqa: E402
 from cedarsim_jl_amd import bsim4_params as B4  # noqa: E402
 from cedarsim_jl_amd import dc_opts, tran_opts  # noqa: E402
 from cedarsim_jl_amd.engine import EngineCircuit  # noqa: E402
-from cedarsim_jl_amd.workloads import CMG_TSPAN, DFF_CHECK_Q, DFF_CHECK_TIMES, cmg_inverter_array, dff_array  # noqa: E402
+from cedarsim_jl_amd.workloads import CMG_TSPAN, DFF_CHECK_Q, DFF_CHECK_TIMES, cmg_inverter_array, dff_array, inverter  # noqa: E402
 
 out = {}
 only = sys.argv[1] if len(sys.argv) > 1 else "all"
+if only in ("all", "config1", "config2"):
+    # config 1 (the reference's plumbing case: one CMOS inverter, DC + transient, gate at 50/150/250/350 ns) and config 2 (one DFF)
+    # are latency cases: one Jacobian block = one wavefront (pair) of the chip; listed for completeness, on both step controllers
+    for name, ckt, tspan, gate_t, gate_v, tol in (("config1_inverter", inverter(), (0.0, 4e-7), (50e-9, 150e-9, 250e-9, 350e-9), (5.0, 0.0, 5.0, 0.0), 1e-8),
+                                                  ("config2_single_dff", dff_array(1, observe="q0"), (0.0, 7e-7), DFF_CHECK_TIMES, DFF_CHECK_Q, 1e-4)):
+        e = EngineCircuit(ckt)
+        entry = {}
+        for stepper in ("host", "device"):
+            opts = tran_opts(abstol=tol, reltol=tol, dc=dc_opts(abstol=1e-14), stepper=stepper)
+            e.tran(tspan[0], tspan[1], opts)
+            t0 = time.perf_counter()
+            rc, t, v, xf, st = e.tran(tspan[0], tspan[1], opts)
+            el = time.perf_counter() - t0
+            q = [float(np.interp(tt, t, v[0, :, 0])) for tt in gate_t]
+            entry[stepper] = {"rc": rc, "wall_seconds": el, "dc_seconds": st["dc_seconds"], "accepted": st["naccept"], "rejected": st["nreject"], "newton_iters": st["nnonliniter"],
+                              "newton_iters_per_sec": st["nnonliniter"] / el, "us_per_attempt": 1e6 * (el - st["dc_seconds"]) / max(1, st["n_step_attempts"]),
+                              "launches": st["n_kernel_launches"], "gate_ok": bool(all(abs(a - b) <= max(10 * tol, 1e-3) for a, b in zip(q, gate_v)))}
+        out[name] = entry
 if only in ("all", "config4"):
     S = 8192
     c = dff_array(1)

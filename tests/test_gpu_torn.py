@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from cedarsim_jl_amd import dc_opts, tran_opts
+from cedarsim_jl_amd import PULSE, Circuit, dc_opts, tran_opts
 from cedarsim_jl_amd.workloads import DFF_CHECK_Q, DFF_CHECK_TIMES, DFF_TSPAN, dff_array, dff_chain
 
 pytestmark = pytest.mark.gpu
@@ -107,3 +107,50 @@ def test_circuits_without_a_border_keep_the_sparse_path(E):
     e = E(dff_chain(8))   # stages coupled through their data nets: no one or two nodes that everything hangs on
     rc, t, v, xf, st = e.tran(0.0, 5e-8, tran_opts(abstol=1e-4, reltol=1e-4))
     assert rc == 0 and st["stepper"] == 1 and e.info()["path"] == 2
+
+
+def rc_tiles(n, rs=20.0):
+    """n RC tiles (own resistance and capacitance each) on one rail that a pulse source drives through rs: the rail is the border
+    (degree n), every tile a block of one unknown — and the border element sees a time-dependent known node."""
+    c = Circuit()
+    c.V("vs", "src", 0, dc=0.0, tran=PULSE(0.0, 1.0, 2e-9, 1e-9, 2e-9, 2e-8, 6e-8))
+    c.R("rs", "src", "rail", rs)
+    c.C("crail", "rail", 0, 5e-13)
+    for i in range(n):
+        c.R("r%d" % i, "rail", "a%d" % i, 1e3 * (1.0 + 0.01 * i))
+        c.C("c%d" % i, "a%d" % i, 0, 1e-12 * (1.0 + 0.02 * (i % 7)))
+    for name in ("rail", "a0", "a%d" % (n - 1)):
+        c.observe_node(name)
+    return c
+
+
+def test_linear_tiles_on_a_pulsed_rail(E, O):
+    """Border of one unknown, blocks of one unknown, a time-dependent source behind the border resistor and a capacitor on the
+    border: torn form against the oracle (dense LU of the whole system) on a saveat grid."""
+    ckt = rc_tiles(80)
+    e = E(ckt)
+    sv = np.linspace(0.0, 1.2e-7, 241)
+    opts = tran_opts(abstol=1e-9, reltol=1e-7, saveat=sv)
+    rc, t, v, xf, st = e.tran(0.0, 1.2e-7, opts)
+    assert rc == 0 and st["stepper"] == 2, (rc, st["stepper"], e.ctx.last_error())
+    assert e.info()["path"] == 2 and e.info()["n_components"] == 1
+    rc_o, t_o, v_o, _, _ = O(ckt).tran(0.0, 1.2e-7, opts)
+    assert rc_o == 0
+    assert np.max(np.abs(v[:, :, 0] - v_o)) < 2e-6, np.max(np.abs(v[:, :, 0] - v_o))
+    assert np.ptp(v[0]) > 0.5 and np.ptp(v[1]) > 0.3   # the rail and the tiles follow the pulse
+
+
+def test_batches_of_a_coupled_array_stay_on_the_sparse_path(E):
+    """The torn form handles one sample; a batch of samples of the coupled array keeps the sparse path (and still runs)."""
+    ckt = coupled(8, 1.0)
+    slot = ckt.slot("rvdd", "r")
+    e = E(ckt)
+    e.set_samples(2)
+    e.set_params([slot], [np.array([1.0, 3.0])])
+    rc, t, v, xf, st = e.tran(DFF_TSPAN[0], 6e-8, tran_opts(abstol=1e-4, reltol=1e-4, saveat=np.linspace(0.0, 6e-8, 13), dc=dc_opts(abstol=1e-12)))
+    assert rc == 0 and st["stepper"] == 1 and v.shape[2] == 2
+    assert np.max(np.abs(v[-2, :, 0] - v[-2, :, 1])) > 3e-8   # the two supply resistances give different rail droops (tiny: a quiet window)
+    e.set_samples(1)
+    rc, t, v1, xf, st = e.tran(DFF_TSPAN[0], 6e-8, tran_opts(abstol=1e-4, reltol=1e-4, saveat=np.linspace(0.0, 6e-8, 13), dc=dc_opts(abstol=1e-12)))
+    assert rc == 0 and st["stepper"] == 2   # back to one sample: the torn form again, with the description's own 1 ohm
+    assert np.max(np.abs(v1[:, :, 0] - v[:, :, 0])) < 1e-3
