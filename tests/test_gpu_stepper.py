@@ -154,6 +154,17 @@ def test_blocks_of_one_circuit_take_their_own_steps_on_a_saveat_grid(E):
     assert np.allclose(x1[0][ok], x2[0][ok], rtol=0, atol=1e-5)
     q = np.array([[np.interp(tt, t1, v1[k, :, 0]) for tt in DFF_CHECK_TIMES] for k in range(tiles)])
     assert np.max(np.abs(q - np.array(DFF_CHECK_Q)[None, :])) < 1e-3
+    os.environ["CEDARHIP_PERSIST_NOPAIR"] = "1"   # the one-wave-per-block instantiation with per-workgroup source tables
+    try:
+        t5, v5, _, st5 = run(e, DFF_TSPAN, "device", **kw)
+    finally:
+        del os.environ["CEDARHIP_PERSIST_NOPAIR"]
+    assert st5["stepper"] == 2 and np.max(np.abs(v5 - v1)) < 1e-5
+    # full size (the bench's skewed-clock variant): 1024 private clocks, every tile through the reference's gate
+    big = E(dff_array(1024, skew=np.random.default_rng(1234).uniform(0.0, 50e-12, 1024), observe="q"))
+    tb, vb, _, stb = run(big, DFF_TSPAN, "auto", abstol=1e-4, reltol=1e-4, saveat=np.array(DFF_CHECK_TIMES), dc=dc_opts(abstol=1e-14))
+    assert stb["stepper"] == 2 and vb.shape == (1024, 5, 1) and stb["n_step_attempts"] < 3000
+    assert np.max(np.abs(vb[:, :, 0] - np.array(DFF_CHECK_Q)[None, :])) <= 10 * 1e-4
     # identical tiles stepped block by block: the same answer in every tile, and the single flip-flop's
     e3 = E(dff_array(6, observe="q"))
     t3, v3, _, st3 = run(e3, DFF_TSPAN, "device", **kw)

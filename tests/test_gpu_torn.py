@@ -154,3 +154,25 @@ def test_batches_of_a_coupled_array_stay_on_the_sparse_path(E):
     rc, t, v1, xf, st = e.tran(DFF_TSPAN[0], 6e-8, tran_opts(abstol=1e-4, reltol=1e-4, saveat=np.linspace(0.0, 6e-8, 13), dc=dc_opts(abstol=1e-12)))
     assert rc == 0 and st["stepper"] == 2   # back to one sample: the torn form again, with the description's own 1 ohm
     assert np.max(np.abs(v1[:, :, 0] - v[:, :, 0])) < 1e-3
+
+
+def test_bordered_form_without_wave_pairs_and_at_full_size(E):
+    """(a) The one-wave-per-block instantiation of the bordered kernel (what arrays of structurally different tiles get), forced
+    with CEDARHIP_PERSIST_NOPAIR, against the paired one.  (b) Property test at the bench's size: the coupled 1024-DFF array,
+    every tile through the reference's logic gate (test/gf180_dff.jl:28-33), rails inside their physical bounds."""
+    e = E(coupled(11, 1.0))
+    sv = np.linspace(0.0, 7e-7, 141)
+    opts = tran_opts(abstol=1e-5, reltol=1e-5, saveat=sv, dc=dc_opts(abstol=1e-12))
+    rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+    os.environ["CEDARHIP_PERSIST_NOPAIR"] = "1"
+    try:
+        rc2, t2, v2, _, st2 = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+    finally:
+        del os.environ["CEDARHIP_PERSIST_NOPAIR"]
+    assert rc == 0 and rc2 == 0 and st["stepper"] == 2 and st2["stepper"] == 2
+    assert (st["naccept"], st["nreject"]) == (st2["naccept"], st2["nreject"]) and np.max(np.abs(v - v2)) < 1e-9
+    big = E(coupled(1024, 1.0))
+    rc, t, v, _, st = big.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, saveat=np.array(DFF_CHECK_TIMES), dc=dc_opts(abstol=1e-12)))
+    assert rc == 0 and st["stepper"] == 2 and v.shape == (1026, 5, 1)
+    assert np.max(np.abs(v[:1024, :, 0] - np.array(DFF_CHECK_Q)[None, :])) <= 10 * 1e-4
+    assert 4.9 < np.min(v[1024]) <= np.max(v[1024]) < 5.0 + 1e-3 and -1e-3 < np.min(v[1025]) <= np.max(v[1025]) < 0.1
