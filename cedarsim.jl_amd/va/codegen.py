@@ -234,14 +234,14 @@ class ModuleGen:
             if vb is None:
                 raise VAError("flow probe %s(%s): only the current of a voltage branch can be probed" % (acc, ",".join(nodes)))
             ty = "real" if ctx.get("noise") else "dual"
-            return ("V[%d]" if vb[1] > 0 else "(-V[%d])") % self.node_ix[vb[0]], ty
+            return ("n%d_" if vb[1] > 0 else "(-n%d_)") % self.node_ix[vb[0]], ty
         for n in nodes:
             if n not in self.node_ix:
                 raise VAError("unknown node '%s' in module %s" % (n, self.m.name))
         ty = "real" if ctx.get("noise") else "dual"
         if len(nodes) == 1:
-            return "V[%d]" % self.node_ix[nodes[0]], ty
-        return "(V[%d] - V[%d])" % (self.node_ix[nodes[0]], self.node_ix[nodes[1]]), ty
+            return "n%d_" % self.node_ix[nodes[0]], ty
+        return "(n%d_ - n%d_)" % (self.node_ix[nodes[0]], self.node_ix[nodes[1]]), ty
 
     def call(self, e, ctx):
         name, args, S = e[1], e[2], ctx["S"]
@@ -456,8 +456,10 @@ class ModuleGen:
                 if ast is None:
                     continue
                 c, t = self.expr(ast, ctx)
-                out.append("%s{ const %s c_ = %s; %s[%d] += c_;%s }" % (pad, S, self.cast(c, t, "dual", S), arr, a,
-                                                                         (" %s[%d] -= c_;" % (arr, b)) if b is not None else ""))
+                acc = arr.lower()   # node sums are kept in locals (i0_, q0_, ...) and stored once at the end: the caller's I[] / Q[]
+                #                     live in scratch (the function is not inlined), a read-modify-write there per contribution
+                out.append("%s{ const %s c_ = %s; %s%d_ += c_;%s }" % (pad, S, self.cast(c, t, "dual", S), acc, a,
+                                                                       (" %s%d_ -= c_;" % (acc, b)) if b is not None else ""))
             return out
         if k == "if":
             c, _ = self.expr(st[1], ctx)
@@ -809,14 +811,18 @@ class ModuleGen:
         out.append("  VA_KEEP_RETURN_ADDRESS;")
         out += param_decls + var_decls("R")
         out.append("  (void)env; (void)V; (void)P; (void)C;")
+        for k in range(len(m.nodes)):   # node voltages read once, node sums accumulated in registers
+            out.append("  const R n%d_ = V[%d]; R i%d_ = R(0.0), q%d_ = R(0.0); (void)n%d_;" % (k, k, k, k, k))
         for k in range(len(m.vbranches)):
             out.append("  int bs%d_ = 0; R bv%d_ = R(0.0), bq%d_ = R(0.0);" % (k, k, k))
         out += E
         for k, key in enumerate(m.vbranches):
             kb, a = self.node_ix[m.branch_node(key)], self.node_ix[key[0]]
-            vab = "V[%d]" % a if len(key) == 1 else "(V[%d] - V[%d])" % (a, self.node_ix[key[1]])
-            out.append("  I[%d] += V[%d];%s" % (a, kb, (" I[%d] -= V[%d];" % (self.node_ix[key[1]], kb)) if len(key) > 1 else ""))
-            out.append("  I[%d] += (bs%d_ == 1 ? %s : V[%d]) - bv%d_; Q[%d] -= bq%d_;" % (kb, k, vab, kb, k, kb, k))
+            vab = "n%d_" % a if len(key) == 1 else "(n%d_ - n%d_)" % (a, self.node_ix[key[1]])
+            out.append("  i%d_ += n%d_;%s" % (a, kb, (" i%d_ -= n%d_;" % (self.node_ix[key[1]], kb)) if len(key) > 1 else ""))
+            out.append("  i%d_ += (bs%d_ == 1 ? %s : n%d_) - bv%d_; q%d_ -= bq%d_;" % (kb, k, vab, kb, k, kb, k))
+        for k in range(len(m.nodes)):
+            out.append("  I[%d] = i%d_; Q[%d] = q%d_;" % (k, k, k, k))
         out.append("}")
         return out
 
@@ -881,6 +887,7 @@ class ModuleGen:
             out.append("  int n_ = 0;")
             out += param_decls + var_decls("double")
             out.append("  (void)env; (void)V; (void)P;")
+            out += ["  const double n%d_ = V[%d]; (void)n%d_;" % (k, k, k) for k in range(len(m.nodes))]
             nctx = {"vars": {k: ("real" if t == "dual" else t) for k, t in vars_.items()}, "S": "double", "noise": True}
             self.dual_saved, self.dual = self.dual, set()
             try:
@@ -898,6 +905,7 @@ class ModuleGen:
             out.append("  VA_KEEP_RETURN_ADDRESS;")
             out += param_decls + var_decls("double")
             out.append("  (void)env; (void)V; (void)P;")
+            out += ["  const double n%d_ = V[%d]; (void)n%d_;" % (k, k, k) for k in range(len(m.nodes))]
             octx = {"vars": {k: ("real" if t == "dual" else t) for k, t in vars_.items()}, "S": "double", "noise": True, "opvars": True}
             saved, self.dual = self.dual, set()
             try:
