@@ -312,11 +312,26 @@ struct ch_circuit {
       // lane slots, expensive devices first so that they share wavefronts: compiled Verilog-A devices take one lane
       // per unknown terminal (direction-parallel duals: lane j computes column j of the stamp Jacobians; derivatives
       // with respect to known nodes are never gathered), MOSFETs and all other devices one lane each
-      for (int d = 0; d < c.ndev; ++d) {
-        const EDev& e = A.edev[A.comp_dofs[rep] + d];
-        if (e.kind != K_VA) continue;
-        bool first = true;
-        for (int j = 0; j < e.nt; ++j) if (e.term[j] >= 0) { blob.push_back((d << 4) | (first ? 8 : 0) | j); first = false; ++ns; }
+      // A block whose compiled devices are large models (BSIM-CMG class) evaluates them in two halves on separate wavefronts:
+      // bit 29 of a slot = split, bit 30 = which half (0: resistive sums and dI/dV, 1: charge sums and dQ/dV); the first halves
+      // fill whole wavefronts (padded with idle slots) so that a wavefront never runs both code paths
+      {
+        std::vector<int> lanes;
+        bool big = false;
+        for (int d = 0; d < c.ndev; ++d) {
+          const EDev& e = A.edev[A.comp_dofs[rep] + d];
+          if (e.kind != K_VA) continue;
+          if (va_gen::MODULES[dev[e.hdev].ipar[0]].n_params >= 64) big = true;
+          bool first = true;
+          for (int j = 0; j < e.nt; ++j) if (e.term[j] >= 0) { lanes.push_back((d << 4) | (first ? 8 : 0) | j); first = false; }
+        }
+        const bool split = big && std::getenv("CEDARHIP_VA_NOSPLIT") == nullptr;
+        if (!split) { for (int v : lanes) { blob.push_back(v); ++ns; } }
+        else {
+          for (int v : lanes) { blob.push_back(v | (1 << 29)); ++ns; }
+          while (ns & 63) { blob.push_back(-1); ++ns; }
+          for (int v : lanes) { blob.push_back(v | (1 << 29) | (1 << 30)); ++ns; }
+        }
       }
       for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind == K_MOS) { blob.push_back(d << 4); ++ns; }
       for (int d = 0; d < c.ndev; ++d) { const int kd = A.edev[A.comp_dofs[rep] + d].kind; if (kd != K_MOS && kd != K_VA) { blob.push_back(d << 4); ++ns; } }

@@ -197,7 +197,7 @@ __device__ __forceinline__ void eval_linear(const EvalCtx& a, int kind, int d, l
 template <bool WIDE>
 __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int slot, const double* xl, int uofs,
                                           const double* kvl, const double* svl, const double* pl, double* stage) {
-  const int dl = slot >> 4;
+  const int dl = (slot >> 4) & 0x01ffffff;
   const int d = dofs + dl;
   double* st_final = stage + (size_t)dl * StampLayout<WIDE>::STRIDE;
   const int kind = a.dkind[d];
@@ -208,7 +208,8 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
     for (int k = 0; k < NTERM; ++k) { const int t = tm[k]; vv[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
     const long pi = (long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0);
     const va::Env env{a.temp_k, a.gmin};
-    va_gen::stamp_dir_c(a.dcls_local[d], a.vapar + a.dsrc[d], a.vacache + a.dvac[d], vv, env, a.dmult[pi], slot & 7, (slot & 8) != 0, st_final);
+    va_gen::stamp_dir_c(a.dcls_local[d], a.vapar + a.dsrc[d], a.vacache + a.dvac[d], vv, env, a.dmult[pi], slot & 7, (slot & 8) != 0,
+                        (slot & (1 << 29)) ? ((slot >> 30) & 1) : -1, st_final);
     return;
   }
   double tmp40[WIDE ? 40 : 1];

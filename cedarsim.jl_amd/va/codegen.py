@@ -458,8 +458,8 @@ class ModuleGen:
                 c, t = self.expr(ast, ctx)
                 acc = arr.lower()   # node sums are kept in locals (i0_, q0_, ...) and stored once at the end: the caller's I[] / Q[]
                 #                     live in scratch (the function is not inlined), a read-modify-write there per contribution
-                out.append("%s{ const %s c_ = %s; %s%d_ += c_;%s }" % (pad, S, self.cast(c, t, "dual", S), acc, a,
-                                                                       (" %s%d_ -= c_;" % (acc, b)) if b is not None else ""))
+                out.append("%sif (PART != %d) { const %s c_ = %s; %s%d_ += c_;%s }" % (pad, 1 if arr == "I" else 0, S, self.cast(c, t, "dual", S), acc, a,
+                                                                                      (" %s%d_ -= c_;" % (acc, b)) if b is not None else ""))
             return out
         if k == "if":
             c, _ = self.expr(st[1], ctx)
@@ -536,7 +536,7 @@ class ModuleGen:
             if ast is None:
                 continue
             c, t = self.expr(ast, ctx)
-            out.append("%s%s%d_ %s %s;" % (pad, var, k, "+=" if sgn > 0 else "-=", self.cast(c, t, "dual", S)))
+            out.append("%sif (PART != %d) %s%d_ %s %s;" % (pad, 1 if var == "bv" else 0, var, k, "+=" if sgn > 0 else "-=", self.cast(c, t, "dual", S)))
         return out
 
     def _decl_suffix(self, name):
@@ -807,7 +807,9 @@ class ModuleGen:
             return ["  %s v_%s%s;" % ({"int": "int", "real": "double", "dual": scalar}[t], nm, self._decl_suffix(nm)) for nm, t in vars_.items()]
         out = ["VA_HD_NOINLINE void setup(const double* P, const va::Env& env, double* C) {", "  VA_KEEP_RETURN_ADDRESS;"]
         out += param_decls + var_decls("double") + ["  (void)env; (void)P; (void)C;"] + S + ["}"]
-        out.append("template <class R> VA_HD_NOINLINE void eval(const double* P, const double* C, const R* V, const va::Env& env, R* I, R* Q) {")
+        # PART: -1 everything; 0 the resistive sums I[] only; 1 the charge sums Q[] only — two half-evaluations on two wavefronts
+        # (the engine's function split of a compiled device: what a half does not store, the compiler drops)
+        out.append("template <class R, int PART> VA_HD_NOINLINE void eval(const double* P, const double* C, const R* V, const va::Env& env, R* I, R* Q) {")
         out.append("  VA_KEEP_RETURN_ADDRESS;")
         out += param_decls + var_decls("R")
         out.append("  (void)env; (void)V; (void)P; (void)C;")
@@ -822,7 +824,7 @@ class ModuleGen:
             out.append("  i%d_ += n%d_;%s" % (a, kb, (" i%d_ -= n%d_;" % (self.node_ix[key[1]], kb)) if len(key) > 1 else ""))
             out.append("  i%d_ += (bs%d_ == 1 ? %s : n%d_) - bv%d_; q%d_ -= bq%d_;" % (kb, k, vab, kb, k, kb, k))
         for k in range(len(m.nodes)):
-            out.append("  I[%d] = i%d_; Q[%d] = q%d_;" % (k, k, k, k))
+            out.append("  if (PART != 1) I[%d] = i%d_; if (PART != 0) Q[%d] = q%d_;" % (k, k, k, k))
         out.append("}")
         return out
 
@@ -977,7 +979,7 @@ def generate_header(modules, source_tag=""):
         for k, node in enumerate(mo.nodes):
             dk = g.ddx_nodes.index(node) if node in g.ddx_nodes else -1
             out.append("      V[%d] = va::seed(v[%d], %d, %d, (R*)nullptr);" % (k, k, k, dk))
-        out.append("      m_%s::eval<R>(P, C, V, env, I, Q);" % mo.name)
+        out.append("      m_%s::eval<R, -1>(P, C, V, env, I, Q);" % mo.name)
         out.append("      scatter<%d, R>(I, Q, m, st);" % nt)
         out.append("    } break;")
     out.append("    default: break;")
@@ -992,7 +994,9 @@ def generate_header(modules, source_tag=""):
     out.append("")
     out.append("// Direction-parallel evaluation: one lane per (device, node j) computes the values and the j-th column of the")
     out.append("// Jacobians with one-directional duals (VD<1,·>); the lane flagged `first` also writes I and Q.")
-    out.append("VA_HD_NOINLINE void stamp_dir_c(int mod, const double* P, const double* C, const double* v, const va::Env& env, double m, int dir, bool first, double* st) {")
+    out.append("// part: -1 the whole record; 0 the resistive half (I, dI/dV); 1 the charge half (Q, dQ/dV) — the two halves of a device may run")
+    out.append("// on different wavefronts.")
+    out.append("VA_HD_NOINLINE void stamp_dir_c(int mod, const double* P, const double* C, const double* v, const va::Env& env, double m, int dir, bool first, int part, double* st) {")
     out.append("  switch (mod) {")
     for i, g in enumerate(gens):
         mo = g.m
@@ -1004,10 +1008,11 @@ def generate_header(modules, source_tag=""):
         for k, node in enumerate(mo.nodes):
             dk = g.ddx_nodes.index(node) if node in g.ddx_nodes else -1
             out.append("      V[%d] = va::seed1(v[%d], dir == %d, %d, (R*)nullptr);" % (k, k, k, dk))
-        out.append("      m_%s::eval<R>(P, C, V, env, I, Q);" % mo.name)
+        out.append("      if (part != 1) m_%s::eval<R, 0>(P, C, V, env, I, Q);" % mo.name)
+        out.append("      if (part != 0) m_%s::eval<R, 1>(P, C, V, env, I, Q);" % mo.name)
         out.append("      for (int k = 0; k < %d; ++k) {" % nt)
-        out.append("        if (first) { st[k] = m * va::val(I[k]); st[8 + k] = m * va::val(Q[k]); }")
-        out.append("        st[16 + k * 8 + dir] = m * va::val(I[k].d[0]); st[80 + k * 8 + dir] = m * va::val(Q[k].d[0]);")
+        out.append("        if (part != 1) { if (first) st[k] = m * va::val(I[k]); st[16 + k * 8 + dir] = m * va::val(I[k].d[0]); }")
+        out.append("        if (part != 0) { if (first) st[8 + k] = m * va::val(Q[k]); st[80 + k * 8 + dir] = m * va::val(Q[k].d[0]); }")
         out.append("      }")
         out.append("    } break;")
     out.append("    default: break;")
