@@ -1057,6 +1057,7 @@ struct ch_circuit {
     std::vector<Rng> rngs; for (int s = 0; s < S; ++s) rngs.emplace_back(o.seed + (uint64_t)s);
     auto block_of_unknown = [&](int u) { int c = (int)(std::upper_bound(A.comp_uofs.begin(), A.comp_uofs.end(), u) - A.comp_uofs.begin()) - 1; return c; };
     int n_active = nblk;
+    std::vector<unsigned char> donor_ok(nblk, 0);   // blocks that converged in this call (their state is a valid starting point for their siblings)
     const int nrest = std::max(1, o.n_restarts);
     for (int r = 0; r < nrest + 1 && n_active > 0; ++r) {
       const bool homotopy = (r == nrest);
@@ -1071,6 +1072,18 @@ struct ch_circuit {
           else for (int i = 0; i < A.n_mna; ++i) xm[i] = 1e-7 * rngs[s].normal();
         } else std::fill(xm.begin(), xm.end(), 0.0);
         for (int u = 0; u < A.n_unk; ++u) if (active[(size_t)block_of_unknown(u) * S + s]) xs[(size_t)s * A.n_unk + u] = xm[A.unk_mna[u]];
+      }
+      // First restart of a batch: a block that did not converge from the random start is started from the operating point of the
+      // same block in a sample that did (continuation from a neighbouring parameter set) — a few iterations instead of another
+      // `maxiters` spent from 1e-7*randn; later restarts are random again as in the reference (src/dcop.jl:53-94).
+      if (r == 1 && S > 1) {
+        for (int c = 0; c < A.n_comp; ++c) {
+          int donor = -1;
+          for (int s = 0; s < S && donor < 0; ++s) if (!active[(size_t)c * S + s] && donor_ok[(size_t)c * S + s]) donor = s;
+          if (donor < 0) continue;
+          for (int s = 0; s < S; ++s) if (active[(size_t)c * S + s])
+            for (int u = A.comp_uofs[c]; u < A.comp_uofs[c] + A.comp_nc[c]; ++u) xs[(size_t)s * A.n_unk + u] = xs[(size_t)donor * A.n_unk + u];
+        }
       }
       HIPCHK(hipMemcpy(d_X.p + (size_t)slot * S * A.n_unk, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(d_active.p, active.data(), nblk, hipMemcpyHostToDevice));
@@ -1089,7 +1102,7 @@ struct ch_circuit {
       if (path == 2) { for (int b = 0; b < nblk; ++b) bo[b].status = sp_status_v[b % S]; }
       else if (host_reduce) std::memcpy(bo.data(), h_out, nblk * sizeof(BlockOut)); else HIPCHK(hipMemcpy(bo.data(), d_out.p, nblk * sizeof(BlockOut), hipMemcpyDeviceToHost));
       n_active = 0;
-      for (int b = 0; b < nblk; ++b) if (active[b]) { if (bo[b].status == 0) active[b] = 0; else ++n_active; }
+      for (int b = 0; b < nblk; ++b) if (active[b]) { if (bo[b].status == 0) { active[b] = 0; donor_ok[b] = 1; } else ++n_active; }
       if (n_active > 0 && stt) { stt->nrestarts++; stt->nnonlinconvfail++; }
     }
     if (status_out) { status_out->assign(S, CH_OK); for (int b = 0; b < nblk; ++b) if (active[b]) (*status_out)[b % S] = bo[b].status == 2 ? CH_ERR_SINGULAR : CH_ERR_MAXITERS; }
