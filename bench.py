@@ -286,9 +286,11 @@ def main():
             # path.  A third, separate measurement: NOT `value`.
             cc = dff_array(args.tiles, observe="q", supply_r=1.0)
             ec = EngineCircuit(cc, ctx)
-            ec.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+            # DC tolerance 1e-12 A: a rail row sums the currents of 15 360 MOSFET terminals, its residual has a rounding floor near 1e-13
+            opts_c = tran_opts(abstol=TOL, reltol=TOL, dc=dc_opts(abstol=1e-12), stepper=args.stepper)
+            ec.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts_c)
             t0c = time.perf_counter()
-            rc_c, t_c, v_c, _, st_c = ec.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+            rc_c, t_c, v_c, _, st_c = ec.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts_c)
             el_c = time.perf_counter() - t0c
             qc = np.array([[np.interp(tt, t_c, v_c[k, :, 0]) for tt in DFF_CHECK_TIMES] for k in range(v_c.shape[0])])
             ic = ec.info()
