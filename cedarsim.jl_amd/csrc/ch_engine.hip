@@ -1112,7 +1112,7 @@ struct ch_circuit {
 
   // ------------------------------------------------------------------------------------------
   // Device-resident step controller: which circuits qualify (ch_persist.hpp header), and the launch.
-  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pkmap, d_psmap;
+  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pwgk;
   int n_cu = 0;
   // `own_steps`: the batch would run with per-sample step acceptance (no grid-wide wait anywhere in the kernel), so the workgroups
   // need not be co-resident and any number of samples can be queued behind each other
@@ -1185,7 +1185,7 @@ struct ch_circuit {
       for (size_t q = 4; q < bi.size(); ++q) if (bi[q] < 0) return false;
       return need.size() <= (size_t)P_MAXSRC && kn.size() + ds.size() <= 64 && pt.size() <= 2048;
     };
-    std::vector<int> wgc, kmap, smap;          // wg_consts: per workgroup {ci offset, cd offset, n_ci, n_cd, bps offset, nbp}; index maps
+    std::vector<int> wgc, wgk;                 // wg_consts: per workgroup {ci offset, cd offset, n_ci, n_cd, bps offset, nbp}; its entries' circuit-wide ids
     std::vector<double> bps_all;
     size_t max_ci = 0, max_cd = 0;
     if (!wg_consts) {
@@ -1194,7 +1194,7 @@ struct ch_circuit {
       if (!build_blob(kn, ds, ci, cd, need)) { set_err("device-resident stepper: the source tables exceed the kernel's limits"); return CH_OK; }
       max_ci = ci.size(); max_cd = cd.size();
     } else {
-      kmap.assign((size_t)n_wg * nk, 0); smap.assign((size_t)n_wg * nds, 0);
+      wgk.assign((size_t)n_wg * P_MAXSRC, -1);   // [wg][entry]: known-node index (entries 0 .. nk_local-1), then device-source slot
       for (int w = 0; w < n_wg; ++w) {
         std::vector<char> uk(nk, 0), ud(nds, 0);
         for (int b = w * PW; b < std::min(nblk, (w + 1) * PW); ++b)
@@ -1204,10 +1204,12 @@ struct ch_circuit {
             if (e.src >= 0) ud[dsrc_host[A.comp_dofs[b] + i]] = 1;
           }
         std::vector<int> kn, ds, need, bi; std::vector<double> bd;
-        for (int k = 0; k < nk; ++k) if (uk[k]) { kmap[(size_t)w * nk + k] = (int)kn.size(); kn.push_back(k); }
-        for (int j = 0; j < nds; ++j) if (ud[j]) { smap[(size_t)w * nds + j] = (int)ds.size(); ds.push_back(j); }
+        for (int k = 0; k < nk; ++k) if (uk[k]) kn.push_back(k);
+        for (int j = 0; j < nds; ++j) if (ud[j]) ds.push_back(j);
         if (ds.empty()) ds.push_back(0);   // the kernel's source-value array is never empty
         if (!build_blob(kn, ds, bi, bd, need)) { set_err("device-resident stepper: a workgroup's blocks reference more than 64 sources / known nodes"); return CH_OK; }
+        for (size_t q = 0; q < kn.size(); ++q) wgk[(size_t)w * P_MAXSRC + q] = kn[q];
+        for (size_t q = 0; q < ds.size(); ++q) wgk[(size_t)w * P_MAXSRC + kn.size() + q] = ds[q];
         std::vector<double> wb;
         for (int i : need) source_breakpoints(src[i], &h_src_par[(size_t)i * CH_SRC_NPAR], t0, t1, wb);
         wb.push_back(t1);
@@ -1229,7 +1231,7 @@ struct ch_circuit {
     else max_rows = std::min<long long>((long long)max_steps + 2, std::max<long long>(1024, std::min<long long>(1 << 20, (long long)((256u << 20) / (row_d * sizeof(double))))));
     if (o.n_saveat == 0 && std::getenv("CEDARHIP_PERSIST_MAXROWS")) max_rows = std::max(2L, std::atol(std::getenv("CEDARHIP_PERSIST_MAXROWS")));   // test hook: forces the drain-and-resume path
     HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(wg_consts ? bps_all : bps, st));
-    if (wg_consts) { HIPCHK(d_pwgc.upload(wgc, st)); HIPCHK(d_pkmap.upload(kmap, st)); HIPCHK(d_psmap.upload(smap, st)); }
+    if (wg_consts) { HIPCHK(d_pwgc.upload(wgc, st)); HIPCHK(d_pwgk.upload(wgk, st)); }
     { std::vector<double> sv(o.saveat, o.saveat + std::max(0, o.n_saveat)); if (sv.empty()) sv.push_back(0.0); HIPCHK(d_psave.upload(sv, st)); }
     HIPCHK(d_ptimes.alloc((size_t)max_rows)); HIPCHK(d_prows.alloc((size_t)max_rows * row_d));
     HIPCHK(d_wgrec.alloc((size_t)2 * n_wg * 16)); HIPCHK(d_grprec.alloc(2 * 8 * 16)); /* 16 granules per record, double-buffered by generation parity */ HIPCHK(d_pcnt.alloc(10 * 32)); HIPCHK(d_pctl.alloc(2));   /* controller state in; [1]: exit state of a batch with per-sample steps */
@@ -1240,7 +1242,7 @@ struct ch_circuit {
     pa.t1 = t1; pa.dtmin = dtmin; pa.dtmax = dtmax; pa.first_frac = 1e-3; pa.kmax = kmax; pa.max_steps = max_steps;
     pa.bps = d_pbps.p; pa.nbp = (int)bps.size(); pa.saveat = d_psave.p; pa.n_saveat = o.n_saveat;
     pa.ci = d_pci.p; pa.cd = d_pcd.p; pa.n_ci = (int)max_ci; pa.n_cd = (int)max_cd;   // layout sizes (the largest workgroup blob)
-    pa.wgc = wg_consts ? d_pwgc.p : nullptr; pa.kmap = wg_consts ? d_pkmap.p : nullptr; pa.smap = wg_consts ? d_psmap.p : nullptr; pa.n_kmap = nk; pa.n_smap = nds;
+    pa.wgc = wg_consts ? d_pwgc.p : nullptr; pa.wgk = wg_consts ? d_pwgk.p : nullptr;
     pa.out_times = d_ptimes.p; pa.out_rows = d_prows.p; pa.max_rows = max_rows; pa.n_obs = n_obs;
     pa.ctl = d_pctl.p; pa.wg_rec = d_wgrec.p; pa.grp_rec = d_grprec.p; pa.counters = d_pcnt.p;
     pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz

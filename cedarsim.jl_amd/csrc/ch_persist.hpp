@@ -55,8 +55,8 @@ struct PersistArgs {
   const int* ci; const double* cd; int n_ci, n_cd;   // constants blob (sources, known-node definitions), copied to LDS
   // per-block steps of ONE circuit: a blob per workgroup with the sources of its own blocks only.  wgc[6 wg ..] = {ci offset,
   // cd offset, n_ci, n_cd, break-point offset, break-point count}; n_ci / n_cd above are then the largest sizes (LDS layout);
-  // kmap[wg][known index] / smap[wg][device-source slot] -> the workgroup's entry numbers
-  const int* wgc; const int* kmap; const int* smap; int n_kmap, n_smap;
+  // wgk[wg][entry] = the circuit-wide known-node index (entries 0 .. nk_local-1) or device-source slot (the rest) of the workgroup's entries
+  const int* wgc; const int* wgk;
   double* out_times; double* out_rows; long long max_rows; int n_obs;
   TranCtl* ctl; int resume;
   double* wg_rec; double* grp_rec; unsigned* counters;   // grid reduction: [n_wg][8], [8][8], 10 counters on 128-byte lines
@@ -498,10 +498,15 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     else if (live && lane < cm.nslots) slot = slots[lane];
     smeta = load_slot_meta(ectx, PAIR ? s_h : s, PAIR ? dofs_h : dofs, PAIR ? uofs_h : uofs, slot);
     if (wgc && smeta.kind != 0) {   // known nodes and device sources by the workgroup's own entry numbers
-      const int* km = p.kmap + (size_t)wg * p.n_kmap; const int* sm = p.smap + (size_t)wg * p.n_smap;
+      const int* wk = p.wgk + (size_t)wg * P_MAXSRC;
+      const int nkl = C.ci[3], nel = C.n_ent();
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (smeta.t[k] < 0) smeta.t[k] = -(km[-smeta.t[k] - 1] + 1);
-      if (smeta.kind == K_I || smeta.kind == K_V) smeta.src = sm[smeta.src];
+      for (int k = 0; k < 4; ++k) if (smeta.t[k] < 0) {
+        const int g = -smeta.t[k] - 1; int j = 0;
+        while (j < nkl - 1 && wk[j] != g) ++j;     // once per transient: at most 64 entries
+        smeta.t[k] = -(j + 1);
+      }
+      if (smeta.kind == K_I || smeta.kind == K_V) { int j = nkl; while (j < nel - 1 && wk[j] != smeta.src) ++j; smeta.src = j - nkl; }
     }
   }
   const int n_ent = C.n_ent();
