@@ -51,7 +51,7 @@ class ChStats(C.Structure):
                                          "naccept", "nreject", "nrestarts")] + \
                [("wall_seconds", C.c_double), ("dc_seconds", C.c_double), ("device_seconds", C.c_double),
                 ("n_kernel_launches", C.c_int64), ("n_block_iters", C.c_int64), ("n_step_attempts", C.c_int64),
-                ("barrier_seconds", C.c_double), ("stepper", C.c_int32), ("pad_", C.c_int32),
+                ("barrier_seconds", C.c_double), ("stepper", C.c_int32), ("stepper_mode", C.c_int32),
                 ("step_kernel_seconds", C.c_double), ("step_kernel_launches", C.c_int64), ("step_block_iters", C.c_int64)]
 
     def asdict(self):

@@ -1113,7 +1113,7 @@ struct ch_circuit {
   // ------------------------------------------------------------------------------------------
   // Device-resident step controller: which circuits qualify (ch_persist.hpp header), and the launch.
   DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pwgk;
-  int n_cu = 0;
+  int n_cu = 0, persist_mode = 0;
   // `own_steps`: the batch would run with per-sample step acceptance (no grid-wide wait anywhere in the kernel), so the workgroups
   // need not be co-resident and any number of samples can be queued behind each other
   bool persist_eligible(std::string& why, bool own_steps) {
@@ -1248,6 +1248,7 @@ struct ch_circuit {
     pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz
     // a batch of single-block samples on a common output grid: every sample its own step sequence (no lock-step, no grid reduction)
     pa.indep = own_steps ? 1 : 0;
+    persist_mode = A.nb > 0 ? CH_MODE_BORDERED : (own_steps ? CH_MODE_OWN_STEPS : CH_MODE_LOCKSTEP);
     pa.nb = A.nb; pa.n_glob = A.n_glob; pa.n_bdev = (int)A.border_dev.size();
     for (int q = 0; q < pa.n_bdev; ++q) {
       const Analysis::BorderDev& bd = A.border_dev[q];
@@ -1606,6 +1607,7 @@ struct ch_circuit {
     R.stats.n_kernel_launches = n_launch + persist_launches;
     R.stats.n_step_attempts += persist_attempts; R.stats.barrier_seconds = persist_barrier_s;
     R.stats.stepper = persist_launches > 0 ? CH_STEPPER_DEVICE : CH_STEPPER_HOST;
+    R.stats.stepper_mode = persist_launches > 0 ? persist_mode : 0;
     R.stats.step_block_iters = R.stats.n_block_iters - dc_block_iters;
     if (persist_launches > 0) { R.stats.step_kernel_seconds = persist_ms * 1e-3; R.stats.step_kernel_launches = persist_launches; }
     else {

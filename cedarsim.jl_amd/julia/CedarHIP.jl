@@ -56,7 +56,7 @@ struct ChStats
     naccept::Int64; nreject::Int64; nrestarts::Int64
     wall_seconds::Float64; dc_seconds::Float64; device_seconds::Float64
     n_kernel_launches::Int64; n_block_iters::Int64; n_step_attempts::Int64
-    barrier_seconds::Float64; stepper::Int32; pad_::Int32
+    barrier_seconds::Float64; stepper::Int32; stepper_mode::Int32
     step_kernel_seconds::Float64; step_kernel_launches::Int64; step_block_iters::Int64
 end
 ChStats() = ChStats(ntuple(_ -> 0, 9)..., 0.0, 0.0, 0.0, 0, 0, 0, 0.0, Int32(0), Int32(0), 0.0, 0, 0)

@@ -162,7 +162,9 @@ typedef struct ch_stats {
   int64_t n_step_attempts; /* time-step attempts (accepted + rejected + Newton failures)                */
   double barrier_seconds;  /* device-resident stepper: time one wave spent inside the grid-wide reductions (0 otherwise) */
   int32_t stepper;         /* which step controller ran: CH_STEPPER_HOST or CH_STEPPER_DEVICE (0 for DC-only calls) */
-  int32_t pad_;
+  int32_t stepper_mode;    /* device-resident stepper: CH_MODE_LOCKSTEP (one step sequence for the whole circuit / batch), CH_MODE_OWN_STEPS
+                              (every independent block / sample its own sequence, output on the saveat grid), CH_MODE_BORDERED (coupled array
+                              torn at its rail nodes: Schur complement on the border inside the kernel); 0 on the host stepper */
   /* the dominant kernel of the call, for roofline accounting: the time-stepping kernel(s) only, DC initialisation excluded */
   double step_kernel_seconds;    /* HIP-event time of those launches (device stepper: exact; host stepper: sampled launches, scaled) */
   int64_t step_kernel_launches;  /* their number (1 per transient on the device stepper, 1 per attempt on the host stepper)         */
@@ -202,6 +204,7 @@ typedef struct ch_tran_opts {
  * launch per step attempt, or inside ONE persistent cooperative launch per transient (blocks stay resident, the
  * accept/reject/order/step decision is taken from a grid-wide reduction by every wavefront identically). */
 enum { CH_STEPPER_AUTO = 0, CH_STEPPER_HOST = 1, CH_STEPPER_DEVICE = 2 };
+enum { CH_MODE_LOCKSTEP = 1, CH_MODE_OWN_STEPS = 2, CH_MODE_BORDERED = 3 };
 
 typedef struct ch_ctx ch_ctx;
 typedef struct ch_circuit ch_circuit;

@@ -31,7 +31,7 @@ def test_single_dff_device_stepper_matches_host_stepper(E):
     kw = dict(abstol=1e-7, reltol=1e-7, saveat=sv, dc=dc_opts(abstol=1e-14))
     th, vh, xh, sth = run(e, DFF_TSPAN, "host", **kw)
     td, vd, xd, std = run(e, DFF_TSPAN, "device", **kw)
-    assert sth["stepper"] == 1 and std["stepper"] == 2
+    assert sth["stepper"] == 1 and std["stepper"] == 2 and std["stepper_mode"] == 1   # one block: CH_MODE_LOCKSTEP
     assert np.array_equal(th, td) and np.array_equal(td, sv)
     assert np.max(np.abs(vh - vd)) < 1e-4 * 5.0, np.max(np.abs(vh - vd))
     ok = ~np.isnan(xh[0])
@@ -146,7 +146,8 @@ def test_blocks_of_one_circuit_take_their_own_steps_on_a_saveat_grid(E):
         t2, v2, x2, st2 = run(e, DFF_TSPAN, "auto", **kw)
     finally:
         del os.environ["CEDARHIP_LOCKSTEP"]
-    assert st1["stepper"] == 2 and v1.shape == (tiles, 141, 1)
+    assert st1["stepper"] == 2 and st1["stepper_mode"] == 2 and v1.shape == (tiles, 141, 1)   # CH_MODE_OWN_STEPS
+    assert st2["stepper_mode"] in (0, 1)                                                         # lock-step (device) or the host stepper
     assert np.max(np.abs(v1 - v2)) < 1e-5, np.max(np.abs(v1 - v2))
     assert st1["n_step_attempts"] < 0.8 * st2["n_step_attempts"]          # no block pays for the others' clock corners
     assert st1["n_block_iters"] < 0.8 * st2["n_block_iters"]

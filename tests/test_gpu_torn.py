@@ -56,7 +56,7 @@ def test_torn_array_takes_the_same_steps_as_the_sparse_path(E, supply_r):
     sv = np.linspace(0.0, 7e-7, 141)
     (t, v, xf, st), (t2, v2, xf2, st2) = both_paths(e, tran_opts(abstol=1e-5, reltol=1e-5, saveat=sv, dc=dc_opts(abstol=1e-12)))
     assert e.info()["path"] == 2 and e.info()["n_components"] == 1   # one coupled block for the structural analysis
-    assert st["stepper"] == 2 and st2["stepper"] == 1          # device-resident stepper on the torn form / host stepper on the sparse path
+    assert st["stepper"] == 2 and st["stepper_mode"] == 3 and st2["stepper"] == 1 and st2["stepper_mode"] == 0   # bordered form on the device stepper / host stepper on the sparse path
     assert (st["naccept"], st["nreject"], st["nnonlinconvfail"]) == (st2["naccept"], st2["nreject"], st2["nnonlinconvfail"])
     assert abs(st["nnonliniter"] - st2["nnonliniter"]) <= 2
     assert np.max(np.abs(v - v2)) < 1e-9, np.max(np.abs(v - v2))
