@@ -176,3 +176,34 @@ def test_bordered_form_without_wave_pairs_and_at_full_size(E):
     assert rc == 0 and st["stepper"] == 2 and v.shape == (1026, 5, 1)
     assert np.max(np.abs(v[:1024, :, 0] - np.array(DFF_CHECK_Q)[None, :])) <= 10 * 1e-4
     assert 4.9 < np.min(v[1024]) <= np.max(v[1024]) < 5.0 + 1e-3 and -1e-3 < np.min(v[1025]) <= np.max(v[1025]) < 0.1
+
+
+def test_torn_form_differential_fuzz(E):
+    """Seeded random arrays (tile count, rail resistances over three decades, one or two rails, decoupling capacitors, tolerance):
+    the bordered form against the sparse path — same controller, same equations, so the same step counts and waveforms."""
+    rng = np.random.default_rng(20260)
+    sv = np.linspace(0.0, 3e-7, 61)
+    for trial in range(6):
+        tiles = int(rng.integers(7, 40))
+        r1 = float(10.0 ** rng.uniform(-1.0, 1.5))
+        r2 = float(10.0 ** rng.uniform(-1.0, 1.5)) if rng.random() < 0.7 else None
+        caps = rng.random() < 0.5
+        tol = float(rng.choice([1e-4, 1e-5]))
+
+        def extra(c, caps=caps):
+            if caps:
+                c.C("cd1", "vdd", 0, 1e-12)
+                if r2 is not None:
+                    c.C("cd2", "vdd", "vss", 5e-13)
+        e = E(coupled(tiles, (r1, r2), extra))
+        os.environ.pop("CEDARHIP_NO_TEAR", None)
+        rc, t, v, xf, st = e.tran(0.0, 3e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, dc=dc_opts(abstol=1e-12)))
+        os.environ["CEDARHIP_NO_TEAR"] = "1"
+        try:
+            rc2, t2, v2, xf2, st2 = e.tran(0.0, 3e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, dc=dc_opts(abstol=1e-12)))
+        finally:
+            del os.environ["CEDARHIP_NO_TEAR"]
+        tag = (trial, tiles, r1, r2, caps, tol)
+        assert rc == 0 and rc2 == 0 and st["stepper_mode"] == 3 and st2["stepper"] == 1, tag
+        assert abs(st["naccept"] - st2["naccept"]) <= 1 and abs(st["nreject"] - st2["nreject"]) <= 1, (tag, st["naccept"], st2["naccept"], st["nreject"], st2["nreject"])
+        assert np.max(np.abs(v - v2)) < 1e-6, (tag, np.max(np.abs(v - v2)))
