@@ -1112,7 +1112,7 @@ struct ch_circuit {
 
   // ------------------------------------------------------------------------------------------
   // Device-resident step controller: which circuits qualify (ch_persist.hpp header), and the launch.
-  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pwgk;
+  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pwgk; DevBuf<double> d_pdcent;
   int n_cu = 0, persist_mode = 0;
   // `own_steps`: the batch would run with per-sample step acceptance (no grid-wide wait anywhere in the kernel), so the workgroups
   // need not be co-resident and any number of samples can be queued behind each other
@@ -1146,8 +1146,10 @@ struct ch_circuit {
     const size_t n_ent = wg_consts ? (size_t)P_MAXSRC : A.known.size() + n_dev_src();
     return lds_doubles_fixed + 16 * (size_t)A.max_nc + 10 + 48 + P_MAXSRC + n_ent + (size_t)max_mc * B4L_STRIDE + (lds_extra_bytes + 7) / 8 + 2;
   }
+  // dcm != nullptr: the operating point of the bordered form instead of a transient (PersistArgs::dc_mode) — the state in ring
+  // slot 0 is the initial iterate and receives the result; no rows, no finish_tran; returns the solve's status
   int tran_persistent(double t0, double t1, const ch_tran_opts& o, ch_result& R, const std::vector<double>& bps, int kmax, double dtmin, double dtmax,
-                      int max_steps, int nmaxit, hclock::time_point tstart, bool& used) {
+                      int max_steps, int nmaxit, hclock::time_point tstart, bool& used, const ch_dc_opts* dcm = nullptr, long long* dc_iters = nullptr) {
     used = false;
     hipStream_t st = ctx->stream;
     g_arena = &arena;
@@ -1230,6 +1232,7 @@ struct ch_circuit {
     if (o.n_saveat > 0) max_rows = (long long)o.n_saveat + 1;
     else max_rows = std::min<long long>((long long)max_steps + 2, std::max<long long>(1024, std::min<long long>(1 << 20, (long long)((256u << 20) / (row_d * sizeof(double))))));
     if (o.n_saveat == 0 && std::getenv("CEDARHIP_PERSIST_MAXROWS")) max_rows = std::max(2L, std::atol(std::getenv("CEDARHIP_PERSIST_MAXROWS")));   // test hook: forces the drain-and-resume path
+    if (dcm) max_rows = 2;
     HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(wg_consts ? bps_all : bps, st));
     if (wg_consts) { HIPCHK(d_pwgc.upload(wgc, st)); HIPCHK(d_pwgk.upload(wgk, st)); }
     { std::vector<double> sv(o.saveat, o.saveat + std::max(0, o.n_saveat)); if (sv.empty()) sv.push_back(0.0); HIPCHK(d_psave.upload(sv, st)); }
@@ -1249,6 +1252,15 @@ struct ch_circuit {
     // a batch of single-block samples on a common output grid: every sample its own step sequence (no lock-step, no grid reduction)
     pa.indep = own_steps ? 1 : 0;
     persist_mode = A.nb > 0 ? CH_MODE_BORDERED : (own_steps ? CH_MODE_OWN_STEPS : CH_MODE_LOCKSTEP);
+    if (dcm) {
+      if (A.nb == 0 || wg_consts) { set_err("internal: operating point on the device stepper is for the bordered form"); return CH_ERR_INTERNAL; }
+      std::vector<double> sv, kv, ent;
+      eval_sources(0.0, dcm->tran_mode ? 2 : 0, sv, kv);
+      ent.assign(kv.begin(), kv.begin() + nk); ent.insert(ent.end(), sv.begin(), sv.begin() + nds);
+      HIPCHK(d_pdcent.upload(ent, st));
+      pa.dc_mode = 1; pa.dc_maxit = std::max(1, dcm->maxiters); pa.dc_abstol = dcm->abstol; pa.dc_entries = d_pdcent.p;
+      pa.dv_max = (!A.mos_hdev.empty() || A.wide) ? dcm->dv_max : 0.0;   // linear circuits take the full Newton step (as on the other paths)
+    }
     pa.nb = A.nb; pa.n_glob = A.n_glob; pa.n_bdev = (int)A.border_dev.size();
     for (int q = 0; q < pa.n_bdev; ++q) {
       const Analysis::BorderDev& bd = A.border_dev[q];
@@ -1306,9 +1318,19 @@ struct ch_circuit {
         HIPCHK(hipMemcpy(hrows.data() + base_t * row_d, d_prows.p, nr * row_d * sizeof(double), hipMemcpyDeviceToHost));
       }
       if (cs.exit_reason == PX_ROWS_FULL) { cs.nsaved = 0; resume = 1; continue; }
-      if (cs.exit_reason == PX_ABORT) { set_err("device-resident stepper: a grid-wide wait exceeded its bound (workgroups not co-resident?)"); status = CH_ERR_DEVICE; }
+      if (cs.exit_reason == PX_ABORT) {
+        unsigned code = 0; (void)hipMemcpy(&code, d_pcnt.p + 9 * 32, sizeof(code), hipMemcpyDeviceToHost);
+        set_err("device-resident stepper: a wait exceeded its bound (site " + std::to_string(code & 255u) + ", sequence " + std::to_string(code >> 8) +
+                ", attempts " + std::to_string((long long)cs.n_attempts) + "; workgroups not co-resident?)");
+        status = CH_ERR_DEVICE;
+      }
       else status = cs.status;
       break;
+    }
+    if (dcm) {
+      if (dc_iters) *dc_iters = cs.sum_iters;
+      if (cs.exit_reason == PX_ABORT && status == CH_OK) status = CH_ERR_DEVICE;
+      return status;
     }
     persist_attempts = cs.n_attempts;
     persist_barrier_s = (double)cs.t_cycles_barrier * 1e-8;
@@ -1329,8 +1351,35 @@ struct ch_circuit {
     return finish_tran(R, 0, cs.t, status, tstart);
   }
 
-  // A coupled array behind a border of one or two unknowns: operating point on this circuit (sparse path), transient on the torn
-  // companion's device-resident stepper.  used = false: the companion does not take the problem (reason in torn_note).
+  // Operating point of the torn form on the device stepper: ONE damped Newton solve (CedarDCOp's first attempt: from o.x0 or
+  // 1e-7*randn) with the Schur complement on the border per iteration.  Any other outcome than CH_OK sends the caller to the
+  // sparse path's full CedarDCOp (restarts, gmin stepping).  The result stays in ring slot 0 of THIS (torn) circuit.
+  bool keep_slot0 = false;
+  int dc_border(const ch_dc_opts& o, long long* iters) {
+    int rc = finalize_params();
+    if (rc != CH_OK) return rc;
+    std::string why;
+    if (!is_torn || !persist_eligible(why, false)) { set_err("bordered operating point: " + why); return CH_ERR_UNSUPPORTED; }
+    std::vector<double> xm((size_t)S * A.n_mna, 0.0);
+    if (o.x0) std::copy(o.x0, o.x0 + xm.size(), xm.begin());
+    else { Rng rng(o.seed); for (double& v : xm) v = 1e-7 * rng.normal(); }
+    rc = upload_from_mna(0, xm.data());
+    if (rc != CH_OK) return rc;
+    ch_tran_opts to; std::memset(&to, 0, sizeof(to));
+    to.abstol = 1e-6; to.reltol = 1e-3; to.max_order = 1;
+    ch_result tmp; tmp.S = S; tmp.n_obs = (int)obs_kind.size();
+    const std::vector<double> one_bp{1.0};
+    const double save_ms = persist_ms; const long save_l = persist_launches;
+    bool used = false;
+    rc = tran_persistent(0.0, 1.0, to, tmp, one_bp, 1, 1e-15, 0.1, 10, 10, hclock::now(), used, &o, iters);
+    persist_ms = save_ms; persist_launches = save_l;
+    if (!used && rc == CH_OK) return CH_ERR_UNSUPPORTED;
+    return rc;
+  }
+
+  // A coupled array behind a border of one or two unknowns: operating point and transient on the torn companion's device-resident
+  // stepper (operating point on this circuit's sparse path when the single damped Newton solve there does not converge).
+  // used = false: the companion does not take the problem (reason in torn_note).
   int tran_torn(double t0, double t1, const ch_tran_opts& o, ch_result& R, bool& used) {
     used = false;
     auto tstart = hclock::now();
@@ -1339,18 +1388,28 @@ struct ch_circuit {
     std::vector<double> x_mna((size_t)S * A.n_mna, 0.0);
     ch_stats dcst; std::memset(&dcst, 0, sizeof(dcst));
     device_ms = 0; n_launch = 0; n_timed = 0;
+    ch_circuit* tc = torn_c.get();
+    bool dc_on_torn = false;
     if (o.skip_dc) { if (o.dc.x0) std::copy(o.dc.x0, o.dc.x0 + x_mna.size(), x_mna.begin()); }
     else {
-      rc = dc_solve(o.dc, 0, nullptr, &dcst);
-      if (rc != CH_OK) { used = true; return rc; }
-      rc = download_mna(0, t0, 1, x_mna.data());
-      if (rc != CH_OK) return rc;
+      if (std::getenv("CEDARHIP_TORN_DC_SPARSE") == nullptr) {
+        long long it = 0;
+        ArenaScope sc(&tc->arena);
+        const int r = tc->dc_border(o.dc, &it);
+        if (r == CH_OK) { dc_on_torn = true; dcst.nnonliniter = it; dcst.nf = dcst.njacs = dcst.nfactors = dcst.nsolve = it; dcst.n_block_iters = it * tc->A.n_comp; }
+        else { torn_note = "bordered operating point: " + err(); ctx->err.clear(); }
+      }
+      if (!dc_on_torn) {
+        rc = dc_solve(o.dc, 0, nullptr, &dcst);
+        if (rc != CH_OK) { used = true; return rc; }
+        rc = download_mna(0, t0, 1, x_mna.data());
+        if (rc != CH_OK) return rc;
+      }
     }
     const double dc_s = std::chrono::duration<double>(hclock::now() - tstart).count();
     const long dc_l = n_launch;
-    ch_tran_opts o2 = o; o2.skip_dc = 1; o2.dc.x0 = x_mna.data(); o2.stepper = CH_STEPPER_DEVICE;
-    ch_circuit* tc = torn_c.get();
-    { ArenaScope sc(&tc->arena); rc = tc->tran_solve(t0, t1, o2, R); }
+    ch_tran_opts o2 = o; o2.skip_dc = 1; o2.dc.x0 = dc_on_torn ? nullptr : x_mna.data(); o2.stepper = CH_STEPPER_DEVICE;
+    { ArenaScope sc(&tc->arena); tc->keep_slot0 = dc_on_torn; rc = tc->tran_solve(t0, t1, o2, R); tc->keep_slot0 = false; }
     if (rc == CH_ERR_UNSUPPORTED) { torn_note = err(); ctx->err.clear(); return CH_OK; }
     used = true;
     R.stats.dc_seconds = dc_s; R.stats.wall_seconds += dc_s; R.stats.n_kernel_launches += dc_l;
@@ -1393,7 +1452,7 @@ struct ch_circuit {
     // ---- initialisation ----
     if (o.skip_dc) {
       if (o.dc.x0) { rc = upload_from_mna(order[0], o.dc.x0); if (rc != CH_OK) return rc; }
-      else HIPCHK(hipMemsetAsync(d_X.p + (size_t)order[0] * S * A.n_unk, 0, (size_t)S * A.n_unk * sizeof(double), st));
+      else if (!keep_slot0) HIPCHK(hipMemsetAsync(d_X.p + (size_t)order[0] * S * A.n_unk, 0, (size_t)S * A.n_unk * sizeof(double), st));
     } else {
       rc = dc_solve(o.dc, order[0], nullptr, &R.stats);
       if (rc != CH_OK) return rc;

@@ -71,6 +71,9 @@ struct PersistArgs {
   int nb, n_glob, n_bdev;     // border unknowns (0: independent blocks), unknowns of the untorn system, devices on the border alone
   int bd_kind[8], bd_ta[8], bd_tb[8];   // K_R / K_C; terminals: >= 0 border index, < 0 -(known index + 1)
   double bd_val[8];           // conductance / capacitance, multiplicity included
+  // Operating point of the bordered form (dc_mode): ONE damped Newton solve at alpha0 = 0 from the state in ring slot 0, entries
+  // (known-node and source values in the operating-point mode) evaluated by the host; result back in slot 0, status in ctl
+  int dc_mode, dc_maxit; double dc_abstol, dv_max; const double* dc_entries;
 };
 
 // ---- constants blob layout -------------------------------------------------------------------
@@ -258,7 +261,7 @@ __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const d
           }
           if (__all(all)) break;
           if (ld_agent_u(abort_flag) != 0u) { ok = false; break; }
-          if (wall_clock64() - t0 > p.spin_ticks) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+          if (wall_clock64() - t0 > p.spin_ticks) { __hip_atomic_store(abort_flag, 1u | (gen << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }   // diagnostic: site 1, generation
           __builtin_amdgcn_s_sleep(1);
         }
         double acc = 0.0;
@@ -283,7 +286,7 @@ __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const d
         }
         if (__all(all) || !ok) break;
         if (ld_agent_u(abort_flag) != 0u) { ok = false; break; }
-        if (wall_clock64() - t0 > p.spin_ticks) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+        if (wall_clock64() - t0 > p.spin_ticks) { __hip_atomic_store(abort_flag, 2u | (gen << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }   // site 2
         __builtin_amdgcn_s_sleep(1);
       }
       double acc = 0.0;
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   typedef StampLayout<false> SL;
   extern __shared__ double lds[];
   __shared__ int s_abort;
+  __shared__ double s_bdec[4];   // bordered form: the border step and residual every wave of the workgroup decides from
   const NewtonArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
   const long long cyc0 = wall_clock64();
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     if (lane == 0) __hip_atomic_store(pf + role, pseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const long long t0w = wall_clock64();
     while (__hip_atomic_load(pf + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pseq) {
-      if (wall_clock64() - t0w > p.spin_ticks) { pair_broken = true; break; }
+      if (wall_clock64() - t0w > p.spin_ticks) { pair_broken = true; __hip_atomic_store(p.counters + 9 * 32, 3u | ((unsigned)pseq << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // site 3
       __builtin_amdgcn_s_sleep(0);
     }
     lds_fence();
@@ -554,7 +558,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     double tn = t + h;
     if (tn >= tb - 1e-3 * h) { tn = tb; hit_bp = true; }
     const double hh = tn - t;
-    if (hh < p.dtmin) { status = CH_ERR_DTMIN; break; }
+    const bool dcm = MODE == PM_BORDER && p.dc_mode != 0;
+    if (!dcm && hh < p.dtmin) { status = CH_ERR_DTMIN; break; }
     const int nh = nhist, kk = k < nh ? k : nh, np = (kk + 1) < nh ? (kk + 1) : nh;
     const bool lte = np >= kk + 1;
     const bool try_up = lte && kk < p.kmax && nh >= kk + 2 && steps_at_order + 1 >= kk + 1;
@@ -562,13 +567,15 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     double alpha0;
     const double cq = p_coef(tn, tsl, head, kk, np, nkm1, nkp1, lte, hh, ln, alpha0);
     const double ck = bcast(cq, 38), ckm1 = bcast(cq, 39), ckp1 = bcast(cq, 40);
+    if (dcm) alpha0 = 0.0;   // operating point: no time derivative
     if (ln < 32) coef[ln] = cq;   // the 26 weights go through LDS: as scalars they would take 52 SGPRs and spill
     lds_fence();
     P_STAMP(1);   // break points, BDF / predictor coefficients
     // entries [known-node values | device source values] at t_new (the sources' left limit when the step lands on a break point)
     {
       const double ts = (hit_bp && tn > 0.0) ? __longlong_as_double(__double_as_longlong(tn) - 1) : (hit_bp ? nextafter(tn, -__builtin_inf()) : tn);
-      if (lane < n_ent) {
+      if (dcm) { if (lane < n_ent) kvl[lane] = p.dc_entries[lane]; }
+      else if (lane < n_ent) {
         double v = 0.0;
         if (e_nt <= 2) {   // the usual case: one or two piecewise-linear sources, their current pieces cached in registers
           if (e_nt > 0) {
@@ -606,6 +613,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         wv[lane] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
       }
     }
+    if (dcm && mine) { xp[lane] = x0; xl[lane] = x0; hq[lane] = 0.0; pm[lane] = x0; pp[lane] = x0; }   // the iterate starts at the state in the ring
     lds_fence();
     P_STAMP(3);   // predictor
 
@@ -617,6 +625,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     constexpr bool bbd = MODE == PM_BORDER;
     const int no = nc - p.nb;                            // the block's own unknowns; lanes no .. nc-1 hold its border replicas
     bool stop_all = false, abort_all = false;            // bordered form: grid-uniform decisions
+    bool dc_bad = false;                                 // operating point: this block's last update left a non-finite value
     double bA = 0.0, bB = 0.0, bC = 0.0, bN = 0.0;       // bordered form: the local-error sums of the last iteration's reduction
     if (live || PAIR || bbd) {
       for (int it = 0; PAIR || bbd || it <= a.maxit; ++it) {
@@ -679,7 +688,9 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         const double fnorm = bcast(row_max<NCR>(fabs(Fi)), 0);
         if (bbd) {
           // ---- (a) partial LU of the block, this block's Schur contribution, grid-wide sum ----
-          bool lfail = live && (!(fnorm == fnorm) || fnorm > 1e300);
+          bool lfail = live && (!(fnorm == fnorm) || fnorm > 1e300 || dc_bad);
+          // operating point: does any OWN row of this block still violate the residual tolerance?
+          const double fown = bcast(row_max<NCR>((mine && lane < no) ? fabs(Fi) : 0.0), 0);
           int piv[NCR]; int mystep; double ipiv;
           if (!lu_bbd_factor<NCR>(r, no, nc, lane, piv, mystep, ipiv)) lfail = live;
           double srec[P_NREC];
@@ -691,14 +702,16 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
             srec[0] = use ? bcast(c0, no) : 0.0; srec[1] = use ? bcast(c1, no) : 0.0; srec[2] = use ? bcast(cr_, no) : 0.0;
             const int l1 = p.nb > 1 ? no + 1 : no;
             srec[3] = (use && p.nb > 1) ? bcast(c0, l1) : 0.0; srec[4] = (use && p.nb > 1) ? bcast(c1, l1) : 0.0; srec[5] = (use && p.nb > 1) ? bcast(cr_, l1) : 0.0;
-            srec[6] = lfail ? 1.0 : 0.0; srec[7] = pair_broken ? 1.0 : 0.0;
+            srec[6] = (lfail ? 1.0 : 0.0) + (pair_broken ? 1048576.0 : 0.0);   // failures; a broken pair wait counts 2^20 (abort)
+            srec[7] = (dcm && live && !(fown < p.dc_abstol)) ? 1.0 : 0.0;        // operating point: blocks whose own rows have not converged
           }
           ++gen;
           const long long cbA = wall_clock64();
           bool okr = p_grid_reduce<true>(p, gen, srec, part, summ, &s_abort, wave, lane, wg);
           double S00 = summ[0], S01 = summ[1], g0 = summ[2], S10 = summ[3], S11 = summ[4], g1 = summ[5];
           const bool gfail = summ[6] != 0.0;
-          if (!okr || summ[7] != 0.0) abort_all = true;
+          const double n_viol = summ[7];
+          if (!okr || summ[6] >= 1048576.0) abort_all = true;
           __syncthreads();   // summ is rewritten by the next reduction
           cyc_bar += wall_clock64() - cbA;
           if (abort_all) break;
@@ -715,6 +728,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
               hb0 = fma(w, (j < kk) ? Xh[sl * nc + no] : 0.0, hb0);
               if (p.nb > 1) hb1 = fma(w, (j < kk) ? Xh[sl * nc + no + 1] : 0.0, hb1);
             }
+            if (dcm) { hb0 = 0.0; hb1 = 0.0; }   // operating point: capacitors carry no current
             for (int q = 0; q < p.n_bdev; ++q) {
               const int ta = p.bd_ta[q], tb = p.bd_tb[q];
               const double va = ta >= 0 ? (ta == 0 ? xb0 : xb1) : kvl[-ta - 1], vb = tb >= 0 ? (tb == 0 ? xb0 : xb1) : kvl[-tb - 1];
@@ -737,7 +751,49 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
             const double det = S00 * S11 - S01 * S10;
             dxb0 = (g0 * S11 - S01 * g1) / det; dxb1 = (S00 * g1 - S10 * g0) / det;
           } else dxb0 = g0 / S00;
+          // Every wave of the grid must take the same decisions from here on.  Waves that own a block hold identical replicas of the
+          // border, so they computed identical numbers; a wave WITHOUT a block (block count not a multiple of 4, or the idle half of
+          // a pair) has no replicas — its LDS region holds whatever an earlier kernel left — and would decide from garbage, leave
+          // the loop at another iteration and dead-lock the reductions.  Wave 0 of every workgroup always owns a block: its
+          // numbers are the workgroup's.  (The write of the next iteration is separated from these reads by the barriers of the
+          // reductions in between.)
+          if (wave == 0 && lane == 0) { s_bdec[0] = dxb0; s_bdec[1] = dxb1; s_bdec[2] = g0; s_bdec[3] = g1; }
+          __syncthreads();
+          dxb0 = s_bdec[0]; dxb1 = s_bdec[1]; g0 = s_bdec[2]; g1 = s_bdec[3];
           if (!(fabs(dxb0) < 1e300) || !(fabs(dxb1) < 1e300)) { nstat = 2; break; }   // singular border (uniform: every wave holds the same numbers)
+          if (dcm) {
+            // ---- operating point: converged when no block reports a violating own row and the reduced border residual is
+            //      below the tolerance (with the own rows converged, g is the border's residual up to O(tolerance)); otherwise a
+            //      damped Newton step (CedarDCOp's voltage limiting) ----
+            if (n_viol == 0.0 && fmax(fabs(g0), fabs(g1)) < p.dc_abstol) { nstat = 0; stop_all = true; continue; }
+            // the full Newton step of every block, then ONE scale for the whole system from the largest node-voltage change
+            // (a second reduction, field 4 = maximum): the same damped iteration as the sparse path's, so the same operating
+            // point of a multi-stable circuit is reached from the same start
+            double dx = 0.0, mo = 0.0;
+            if (live) {
+              dx = lu_bbd_back<NCR>(r, no, nc, lane, piv, mystep, ipiv, dxb0, dxb1);
+              mo = bcast(row_max<NCR>((mine && lane < no && !(dml[lane] & 2)) ? fabs(dx) : 0.0), 0);
+              if (__ballot(mine && !(dx == dx))) dc_bad = true;
+            }
+            double brec[P_NREC] = {0.0, 0.0, 0.0, 0.0, mo, 0.0, 0.0, 0.0};
+            ++gen;
+            const long long cbD = wall_clock64();
+            const bool okd = p_grid_reduce(p, gen, brec, part, summ, &s_abort, wave, lane, wg);
+            const double gmax = fmax(summ[4], fmax(fabs(dxb0), fabs(dxb1)));
+            __syncthreads();
+            cyc_bar += wall_clock64() - cbD;
+            if (!okd) { abort_all = true; break; }
+            const double sc = (p.dv_max > 0.0 && gmax > p.dv_max) ? p.dv_max / gmax : 1.0;
+            if (live) {
+              const double xn = xi + sc * dx;
+              if (mine) xl[lane] = xn;
+              if (__ballot(mine && (!(xn == xn) || fabs(xn) > 1e300))) dc_bad = true;
+            }
+            ++iters;
+            if (it + 1 >= p.dc_maxit) stop_all = true;   // not converged: nstat stays 1
+            lds_fence();
+            continue;
+          }
           // ---- (d) back substitution, update, charges, norms ----
           double e2own = 0.0, l2k = 0.0, l2m = 0.0, l2p = 0.0, lnd = 0.0, lbad = 0.0;
           if (live) {
@@ -816,6 +872,15 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         P_STAMP(8);   // update, charge, convergence test
         if (stop) { if (PAIR) done_own = true; else break; }
       }
+    }
+    if (dcm) {   // the operating point goes back to the ring slot it came from; the host reads the status
+      if (abort_all) { exit_reason = PX_ABORT; status = CH_ERR_DEVICE; break; }
+      if (mine) Xh[head * nc + lane] = xl[lane];
+      if (lane == 0) { stl[ST_ITERS] += iters; stl[ST_BITERS] += (long long)iters * p.nblk; }
+      lds_fence();
+      status = nstat == 0 ? CH_OK : (nstat == 2 ? CH_ERR_SINGULAR : CH_ERR_MAXITERS);
+      exit_reason = PX_DONE;
+      break;
     }
     // ---- candidate into the ring, local-error sums (the block's unknowns sit in the first 16 lanes: DPP row sums) ----
     double e2k = 0.0, e2m = 0.0, e2p = 0.0, ndf = 0.0;

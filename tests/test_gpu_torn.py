@@ -27,8 +27,15 @@ def O():
 
 
 def both_paths(e, opts):
+    """The same transient on the bordered form and on the sparse path, BOTH started from the sparse path's operating point
+    (CEDARHIP_TORN_DC_SPARSE): identical initial states, so the two solvers can be held to identical step sequences.  The bordered
+    form's own operating point is checked in test_bordered_operating_point."""
     os.environ.pop("CEDARHIP_NO_TEAR", None)
-    rc, t, v, xf, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+    os.environ["CEDARHIP_TORN_DC_SPARSE"] = "1"
+    try:
+        rc, t, v, xf, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+    finally:
+        del os.environ["CEDARHIP_TORN_DC_SPARSE"]
     assert rc == 0, (rc, e.ctx.last_error())
     os.environ["CEDARHIP_NO_TEAR"] = "1"
     try:
@@ -197,7 +204,11 @@ def test_torn_form_differential_fuzz(E):
                     c.C("cd2", "vdd", "vss", 5e-13)
         e = E(coupled(tiles, (r1, r2), extra))
         os.environ.pop("CEDARHIP_NO_TEAR", None)
-        rc, t, v, xf, st = e.tran(0.0, 3e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, dc=dc_opts(abstol=1e-12)))
+        os.environ["CEDARHIP_TORN_DC_SPARSE"] = "1"   # both from the sparse path's operating point: identical initial states
+        try:
+            rc, t, v, xf, st = e.tran(0.0, 3e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, dc=dc_opts(abstol=1e-12)))
+        finally:
+            del os.environ["CEDARHIP_TORN_DC_SPARSE"]
         os.environ["CEDARHIP_NO_TEAR"] = "1"
         try:
             rc2, t2, v2, xf2, st2 = e.tran(0.0, 3e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, dc=dc_opts(abstol=1e-12)))
@@ -207,3 +218,24 @@ def test_torn_form_differential_fuzz(E):
         assert rc == 0 and rc2 == 0 and st["stepper_mode"] == 3 and st2["stepper"] == 1, tag
         assert abs(st["naccept"] - st2["naccept"]) <= 1 and abs(st["nreject"] - st2["nreject"]) <= 1, (tag, st["naccept"], st2["naccept"], st["nreject"], st2["nreject"])
         assert np.max(np.abs(v - v2)) < 1e-6, (tag, np.max(np.abs(v - v2)))
+
+
+@pytest.mark.parametrize("tiles,supply_r", [(9, 1.0), (12, (3.0, None)), (30, 0.2)])
+def test_bordered_operating_point(E, tiles, supply_r):
+    """The operating point of the torn form — one damped Newton solve with the Schur complement on the border, the same uniform
+    voltage limiting as the sparse path — against the sparse path's: the state at t = 0 (first saveat row) and the waveforms.  Tile
+    counts that leave workgroups partly empty (9, 30) exercise the waves that own no block."""
+    e = E(coupled(tiles, supply_r))
+    sv = np.linspace(0.0, 2e-7, 41)
+    opts = tran_opts(abstol=1e-7, reltol=1e-7, saveat=sv, dc=dc_opts(abstol=1e-12))
+    os.environ.pop("CEDARHIP_TORN_DC_SPARSE", None)
+    rc, t, v, xf, st = e.tran(0.0, 2e-7, opts)
+    os.environ["CEDARHIP_TORN_DC_SPARSE"] = "1"
+    try:
+        rc2, t2, v2, xf2, st2 = e.tran(0.0, 2e-7, opts)
+    finally:
+        del os.environ["CEDARHIP_TORN_DC_SPARSE"]
+    assert rc == 0 and rc2 == 0 and st["stepper_mode"] == 3 and st2["stepper_mode"] == 3
+    assert np.max(np.abs(v[:, 0, 0] - v2[:, 0, 0])) < 1e-8, np.max(np.abs(v[:, 0, 0] - v2[:, 0, 0]))   # the same operating point (the same latch states)
+    assert np.max(np.abs(v - v2)) < 1e-5
+    assert st["dc_seconds"] < st2["dc_seconds"]
