@@ -287,7 +287,8 @@ def main():
             cc = dff_array(args.tiles, observe="q", supply_r=1.0)
             ec = EngineCircuit(cc, ctx)
             # DC tolerance 1e-12 A: a rail row sums the currents of 15 360 MOSFET terminals, its residual has a rounding floor near 1e-13
-            opts_c = tran_opts(abstol=TOL, reltol=TOL, dc=dc_opts(abstol=1e-12), stepper=args.stepper)
+            # (output on the gate times: with every accepted step of 1024 observables saved, 9 MB of rows per transient cross PCIe)
+            opts_c = tran_opts(abstol=TOL, reltol=TOL, dc=dc_opts(abstol=1e-12), stepper=args.stepper, saveat=np.array(DFF_CHECK_TIMES))
             ec.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts_c)
             t0c = time.perf_counter()
             rc_c, t_c, v_c, _, st_c = ec.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts_c)

@@ -1356,22 +1356,29 @@ struct ch_circuit {
   // sparse path's full CedarDCOp (restarts, gmin stepping).  The result stays in ring slot 0 of THIS (torn) circuit.
   bool keep_slot0 = false;
   int dc_border(const ch_dc_opts& o, long long* iters) {
+    const auto td0 = hclock::now();
+    auto lap = [&](const char* what) { if (std::getenv("CEDARHIP_DEBUG_TORN")) std::fprintf(stderr, "[torn] dc_border %s at %.3f ms\n", what, 1e3 * std::chrono::duration<double>(hclock::now() - td0).count()); };
     int rc = finalize_params();
     if (rc != CH_OK) return rc;
+    lap("finalized");
     std::string why;
     if (!is_torn || !persist_eligible(why, false)) { set_err("bordered operating point: " + why); return CH_ERR_UNSUPPORTED; }
     std::vector<double> xm((size_t)S * A.n_mna, 0.0);
     if (o.x0) std::copy(o.x0, o.x0 + xm.size(), xm.begin());
     else { Rng rng(o.seed); for (double& v : xm) v = 1e-7 * rng.normal(); }
+    lap("start vector");
     rc = upload_from_mna(0, xm.data());
     if (rc != CH_OK) return rc;
+    lap("uploaded");
     ch_tran_opts to; std::memset(&to, 0, sizeof(to));
     to.abstol = 1e-6; to.reltol = 1e-3; to.max_order = 1;
     ch_result tmp; tmp.S = S; tmp.n_obs = (int)obs_kind.size();
     const std::vector<double> one_bp{1.0};
     const double save_ms = persist_ms; const long save_l = persist_launches;
     bool used = false;
+    const auto tq0 = hclock::now();
     rc = tran_persistent(0.0, 1.0, to, tmp, one_bp, 1, 1e-15, 0.1, 10, 10, hclock::now(), used, &o, iters);
+    if (std::getenv("CEDARHIP_DEBUG_TORN")) std::fprintf(stderr, "[torn] dc_border: kernel %.3f ms, call %.3f ms\n", persist_ms - save_ms, 1e3 * std::chrono::duration<double>(hclock::now() - tq0).count());
     persist_ms = save_ms; persist_launches = save_l;
     if (!used && rc == CH_OK) return CH_ERR_UNSUPPORTED;
     return rc;
@@ -1398,6 +1405,8 @@ struct ch_circuit {
         const int r = tc->dc_border(o.dc, &it);
         if (r == CH_OK) { dc_on_torn = true; dcst.nnonliniter = it; dcst.nf = dcst.njacs = dcst.nfactors = dcst.nsolve = it; dcst.n_block_iters = it * tc->A.n_comp; }
         else { torn_note = "bordered operating point: " + err(); ctx->err.clear(); }
+        if (std::getenv("CEDARHIP_DEBUG_TORN")) std::fprintf(stderr, "[torn] operating point on the device stepper: rc %d, %lld iterations, %.3f ms%s%s\n", r, it,
+                                                             1e3 * std::chrono::duration<double>(hclock::now() - tstart).count(), r == CH_OK ? "" : " -> sparse path: ", r == CH_OK ? "" : torn_note.c_str());
       }
       if (!dc_on_torn) {
         rc = dc_solve(o.dc, 0, nullptr, &dcst);
