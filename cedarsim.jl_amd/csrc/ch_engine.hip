@@ -1114,6 +1114,7 @@ struct ch_circuit {
   // Device-resident step controller: which circuits qualify (ch_persist.hpp header), and the launch.
   DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pwgk; DevBuf<double> d_pdcent;
   int n_cu = 0, persist_mode = 0;
+  bool persist_aborted = false;   // the last device-stepper launch gave up on a wait (its workgroups were not co-resident: another process's kernel held part of the GPU)
   // `own_steps`: the batch would run with per-sample step acceptance (no grid-wide wait anywhere in the kernel), so the workgroups
   // need not be co-resident and any number of samples can be queued behind each other
   bool persist_eligible(std::string& why, bool own_steps) {
@@ -1319,6 +1320,7 @@ struct ch_circuit {
       }
       if (cs.exit_reason == PX_ROWS_FULL) { cs.nsaved = 0; resume = 1; continue; }
       if (cs.exit_reason == PX_ABORT) {
+        persist_aborted = true;
         unsigned code = 0; (void)hipMemcpy(&code, d_pcnt.p + 9 * 32, sizeof(code), hipMemcpyDeviceToHost);
         set_err("device-resident stepper: a wait exceeded its bound (site " + std::to_string(code & 255u) + ", sequence " + std::to_string(code >> 8) +
                 ", attempts " + std::to_string((long long)cs.n_attempts) + "; workgroups not co-resident?)");
@@ -1419,7 +1421,7 @@ struct ch_circuit {
     const long dc_l = n_launch;
     ch_tran_opts o2 = o; o2.skip_dc = 1; o2.dc.x0 = dc_on_torn ? nullptr : x_mna.data(); o2.stepper = CH_STEPPER_DEVICE;
     { ArenaScope sc(&tc->arena); tc->keep_slot0 = dc_on_torn; rc = tc->tran_solve(t0, t1, o2, R); tc->keep_slot0 = false; }
-    if (rc == CH_ERR_UNSUPPORTED) { torn_note = err(); ctx->err.clear(); return CH_OK; }
+    if (rc == CH_ERR_UNSUPPORTED || (rc == CH_ERR_DEVICE && tc->persist_aborted)) { torn_note = err(); ctx->err.clear(); return CH_OK; }   // the sparse path takes it
     used = true;
     R.stats.dc_seconds = dc_s; R.stats.wall_seconds += dc_s; R.stats.n_kernel_launches += dc_l;
     R.stats.nf += dcst.nf; R.stats.njacs += dcst.njacs; R.stats.nfactors += dcst.nfactors; R.stats.nsolve += dcst.nsolve;
@@ -1495,7 +1497,18 @@ struct ch_circuit {
         std::string why;
         if (persist_eligible(why, persist_own_steps(o))) {
           bool used = false;
+          persist_aborted = false;
           rc = tran_persistent(t0, t1, o, R, bps, kmax, dtmin, dtmax, max_steps, nmaxit, tstart, used);
+          if (used && persist_aborted && want != CH_STEPPER_DEVICE) {
+            // A grid-wide wait ran into its bound: the cooperative launch shared the GPU with another process's kernel and
+            // its workgroups were not all resident.  The solve is repeated on the host stepper (whose launches need no
+            // co-residency); the torn form hands back to the sparse path of its parent.
+            const std::string msg = err();
+            ctx->err.clear();
+            if (is_torn) { set_err(msg); return CH_ERR_UNSUPPORTED; }
+            ch_tran_opts o3 = o; o3.stepper = CH_STEPPER_HOST;
+            return tran_solve(t0, t1, o3, R);
+          }
           if (used) return rc;
           why = err();
         }

@@ -198,3 +198,38 @@ def test_device_stepper_is_refused_where_it_cannot_run(E):
     assert rc == -6 and "device-resident stepper" in e.ctx.last_error()
     rc, t, v, xf, st = e.tran(0.0, 1e-8, tran_opts())   # auto: falls back to the host stepper
     assert rc == 0 and st["stepper"] == 1
+
+
+SHARED_GPU_WORKER = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from cedarsim_jl_amd import dc_opts, tran_opts
+from cedarsim_jl_amd.engine import EngineCircuit, load_library
+from cedarsim_jl_amd.workloads import DFF_CHECK_Q, DFF_CHECK_TIMES, dff_array
+load_library()
+e = EngineCircuit(dff_array(1024, observe="q0"))
+modes = []
+for k in range(3):
+    rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14)))
+    assert rc == 0, (rc, e.ctx.last_error())
+    q = [float(np.interp(tt, t, v[0, :, 0])) for tt in DFF_CHECK_TIMES]
+    assert all(abs(a - b) <= 1e-3 for a, b in zip(q, DFF_CHECK_Q)), q
+    modes.append(st["stepper"])
+print("SHARED_GPU_OK", modes)
+"""
+
+
+def test_two_processes_share_the_gpu(tmp_path):
+    """The device-resident stepper is a cooperative launch that takes the whole chip.  When another process's kernel holds part of
+    it the workgroups are not all resident, a grid-wide wait runs into its bound, and the solve is repeated on the host stepper:
+    two processes solving the 1024-DFF array at the same time must both come back with rc 0 and the reference's gate."""
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text(SHARED_GPU_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, str(script), root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "SHARED_GPU_OK" in so, so[-1500:] + se[-1500:]
