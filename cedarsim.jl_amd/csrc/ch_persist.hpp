@@ -11,9 +11,16 @@
 // variable-coefficient BDF / predictor weights are evaluated on the device, lane-parallel.
 //
 // Residency: n_wg workgroups of 4 waves, one workgroup per CU (<= 1024 blocks); the launch is cooperative, so a grid that
-// cannot be co-resident is refused by the runtime instead of dead-locking, and every spin is bounded by a wall-clock limit.
-// Shapes handled: S == 1 (one circuit of independent blocks: the error norm is the WRMS over ALL blocks) or n_comp == 1
-// (a batch of single-block samples: per-sample WRMS, maximum over samples).  Everything else keeps the host stepper.
+// cannot be co-resident is refused by the runtime instead of dead-locking, and every spin is bounded by a wall-clock limit
+// (a launch that shared the GPU with another process gives up there and the host repeats the solve on the host stepper).
+// Three forms, separate instantiations of one kernel (template parameter MODE):
+//   PM_LOCKSTEP  one step sequence for the whole grid — S == 1 (one circuit of independent blocks: the error norm is the WRMS over
+//                ALL blocks) or n_comp == 1 (a batch of single-block samples: per-sample WRMS, maximum over samples);
+//   PM_OWN       output on a saveat grid: every sample / block (pair) its own controller and step sequence, no grid-wide
+//                reduction, any number of queued workgroups, per-workgroup source tables and break points for one circuit;
+//   PM_BORDER    a coupled array torn at one or two border unknowns (ch_analysis.hpp): register LU per block + a grid-wide Schur
+//                complement per Newton iteration, transient and operating point.
+// Everything else keeps the host stepper.
 #pragma once
 #include <hip/hip_runtime.h>
 

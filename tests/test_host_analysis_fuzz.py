@@ -28,3 +28,36 @@ def test_sparse_analysis_is_sanitizer_clean_on_random_matrices(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "fail 0" in r.stdout
+
+
+def test_return_address_scanner_flags_the_pattern(tmp_path):
+    """scripts/check_return_address.py on two hand-written device functions: one whose long-branch expansion writes s[30:31]
+    without a saved copy (the code-generator defect worked around in csrc/va_rt.hpp), one that saved the pair first."""
+    import subprocess
+    import sys
+    bad = """
+_Z3badv: ; @_Z3badv
+\ts_waitcnt vmcnt(0)
+\ts_getpc_b64 s[30:31]
+.Lpost_getpc1:
+\ts_add_u32 s30, s30, (.LBB0_2-.Lpost_getpc1)&4294967295
+\ts_setpc_b64 s[30:31]
+.LBB0_2:
+\ts_setpc_b64 s[30:31]
+\t.size\t_Z3badv, .Lfunc_end0-_Z3badv
+_Z4goodv: ; @_Z4goodv
+\tv_writelane_b32 v255, s30, 0
+\tv_writelane_b32 v255, s31, 1
+\ts_getpc_b64 s[30:31]
+\ts_setpc_b64 s[30:31]
+\tv_readlane_b32 s30, v255, 0
+\ts_setpc_b64 s[30:31]
+\t.size\t_Z4goodv, .Lfunc_end1-_Z4goodv
+"""
+    f = tmp_path / "dev.s"
+    f.write_text(bad)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_return_address.py"), str(f)], capture_output=True, text=True)
+    assert r.returncode == 1 and "_Z3badv" in r.stdout and "_Z4goodv" not in r.stdout.split("checked")[0].replace("_Z3badv", ""), r.stdout
+    f.write_text(bad.split("_Z4goodv: ; @_Z4goodv")[0].replace("s_getpc_b64 s[30:31]", "s_getpc_b64 s[98:99]"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_return_address.py"), str(f)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
