@@ -824,7 +824,8 @@ class ModuleGen:
             out.append("  i%d_ += n%d_;%s" % (a, kb, (" i%d_ -= n%d_;" % (self.node_ix[key[1]], kb)) if len(key) > 1 else ""))
             out.append("  i%d_ += (bs%d_ == 1 ? %s : n%d_) - bv%d_; q%d_ -= bq%d_;" % (kb, k, vab, kb, k, kb, k))
         for k in range(len(m.nodes)):
-            out.append("  if (PART != 1) I[%d] = i%d_; if (PART != 0) Q[%d] = q%d_;" % (k, k, k, k))
+            out.append("  if (PART != 1) I[%d] = i%d_;" % (k, k))
+            out.append("  if (PART != 0) Q[%d] = q%d_;" % (k, k))
         out.append("}")
         return out
 
