@@ -1112,7 +1112,7 @@ struct ch_circuit {
 
   // ------------------------------------------------------------------------------------------
   // Device-resident step controller: which circuits qualify (ch_persist.hpp header), and the launch.
-  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pwgk; DevBuf<double> d_pdcent;
+  DevBuf<int> d_pci; DevBuf<double> d_pcd, d_pbps, d_psave, d_ptimes, d_prows, d_wgrec, d_grprec; DevBuf<unsigned> d_pcnt; DevBuf<TranCtl> d_pctl; DevBuf<int> d_pwgc, d_pwgk; DevBuf<double> d_pdcent, d_ptrans;
   int n_cu = 0, persist_mode = 0;
   bool persist_aborted = false;   // the last device-stepper launch gave up on a wait (its workgroups were not co-resident: another process's kernel held part of the GPU)
   // `own_steps`: the batch would run with per-sample step acceptance (no grid-wide wait anywhere in the kernel), so the workgroups
@@ -1288,6 +1288,7 @@ struct ch_circuit {
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((160 * 1024 - (int)fa.sharedSizeBytes) & ~255)));
     }
     std::vector<double> hrows, htimes;
+    bool single_batch = false;
     std::vector<std::vector<double>> row_store;   // drained batches when the row buffer fills (no saveat)
     int resume = 0, status = CH_OK;
     for (;;) {
@@ -1313,10 +1314,15 @@ struct ch_circuit {
       // rows of this launch
       const size_t nr = (size_t)cs.nsaved;
       const size_t base_t = htimes.size();
-      htimes.resize(base_t + nr); hrows.resize((base_t + nr) * row_d);
+      // The usual case — the whole transient in one launch: the rows are transposed on the device into the result's layout
+      // [observable][time][sample] and cross PCIe once, straight into the result (the host-side transposition of a result with
+      // every node observed, 100 MB for the 1024-DFF array, cost several times the solve).  Drained batches keep the host path.
+      single_batch = resume == 0 && cs.exit_reason != PX_ROWS_FULL && !dcm;
+      htimes.resize(base_t + nr);
+      if (!single_batch) hrows.resize((base_t + nr) * row_d);
       if (nr > 0) {
         HIPCHK(hipMemcpy(htimes.data() + base_t, d_ptimes.p, nr * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hrows.data() + base_t * row_d, d_prows.p, nr * row_d * sizeof(double), hipMemcpyDeviceToHost));
+        if (!single_batch) HIPCHK(hipMemcpy(hrows.data() + base_t * row_d, d_prows.p, nr * row_d * sizeof(double), hipMemcpyDeviceToHost));
       }
       if (cs.exit_reason == PX_ROWS_FULL) { cs.nsaved = 0; resume = 1; continue; }
       if (cs.exit_reason == PX_ABORT) {
@@ -1349,6 +1355,16 @@ struct ch_circuit {
     const size_t nt = htimes.size();
     R.times = htimes;
     R.values.assign((size_t)n_obs * nt * S, 0.0);
+    if (single_batch) {
+      const size_t n = (size_t)n_obs * nt * S;
+      if (n > 0) {
+        HIPCHK(d_ptrans.alloc(n));
+        hipLaunchKernelGGL(transpose_rows_kernel, dim3((unsigned)std::min<size_t>(65535, (n + 255) / 256)), dim3(256), 0, st, (const double*)d_prows.p, d_ptrans.p, (long)nt, (long)n_obs, S);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(R.values.data(), d_ptrans.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+      }
+    } else
     for (size_t r = 0; r < nt; ++r) for (int ob = 0; ob < n_obs; ++ob) std::memcpy(&R.values[((size_t)ob * nt + r) * S], &hrows[(r * n_obs + ob) * S], S * sizeof(double));
     return finish_tran(R, 0, cs.t, status, tstart);
   }

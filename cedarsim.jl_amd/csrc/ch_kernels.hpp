@@ -1003,6 +1003,15 @@ __global__ __launch_bounds__(256) void reduce_blocks_kernel(const NewtonArgs a) 
 }
 
 // Save observables: out[o*S + s] = Σ_j w[j] X[slot_j][s][idx_o]  (idx < 0 → NaN placeholder, filled on host)
+// saved rows [time][observable][sample] -> the result's layout [observable][time][sample] (writes coalesced)
+__global__ void transpose_rows_kernel(const double* in, double* out, long nt, long ncol, int S) {
+  const long n = nt * ncol * S;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+    const long s = o % S, rc = o / S, r = rc % nt, c = rc / nt;
+    out[o] = in[(r * ncol + c) * S + s];
+  }
+}
+
 struct ObsArgs { const double* X; long slot_stride; int slots[8]; double w[8]; int nw; int n_unk, S, n_obs; const int* obs_unk; double* dst; };
 __global__ void save_obs_kernel(const ObsArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
