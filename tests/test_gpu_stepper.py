@@ -174,6 +174,26 @@ def test_blocks_of_one_circuit_take_their_own_steps_on_a_saveat_grid(E):
     assert np.max(np.abs(v3 - v3[0:1])) < 1e-9 and np.max(np.abs(v3[0] - v4[0])) < 1e-6
 
 
+def test_own_steps_against_the_oracle(E):
+    """Per-block steps against the oracle (which integrates the whole circuit with one step sequence, dense LU): six tiles with
+    private, skewed clocks, waveforms of every tile within 1e-4 of the swing."""
+    from oracle_binding import Oracle
+    rng = np.random.default_rng(7)
+    ckt = dff_array(6, skew=rng.uniform(0.0, 50e-12, 6), observe="q")
+    sv = np.linspace(0.0, 7e-7, 141)
+    e = E(ckt)
+    # both from the SAME operating point: the flip-flops' latches are bistable at t = 0, and the two DC solvers (block-wise restarts
+    # here, one system in the oracle) need not pick the same state from their random starts
+    rc, x0, _, _ = e.dc(dc_opts(abstol=1e-14))
+    assert rc == 0
+    x0 = np.nan_to_num(x0, nan=0.0)
+    rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, skip_dc=True, dc=dc_opts(x0=x0)))
+    assert rc == 0 and st["stepper_mode"] == 2
+    rc_o, t_o, v_o, _, _ = Oracle(ckt).tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, skip_dc=True, dc=dc_opts(x0=x0[0])))
+    assert rc_o == 0
+    assert np.max(np.abs(v[:, :, 0] - v_o)) < 1e-4 * 5.0, np.max(np.abs(v[:, :, 0] - v_o))
+
+
 def test_row_buffer_drain_and_resume(E):
     """Without saveat every accepted step is a row; when the device row buffer fills, the kernel stops with its controller state
     and history written back and the host relaunches it (resume): the result must not depend on where the cuts fall."""
