@@ -194,6 +194,32 @@ def test_own_steps_against_the_oracle(E):
     assert np.max(np.abs(v[:, :, 0] - v_o)) < 1e-4 * 5.0, np.max(np.abs(v[:, :, 0] - v_o))
 
 
+def test_own_steps_differential_fuzz(E):
+    """Seeded random skewed arrays (tile count incl. counts that leave waves and pairs without a block, skew range, tolerance,
+    with and without the function split across wave pairs): per-block steps against the lock-step controller."""
+    rng = np.random.default_rng(4242)
+    sv = np.linspace(0.0, 4.2e-7, 85)
+    for trial in range(5):
+        tiles = int(rng.integers(3, 31))
+        skew = rng.uniform(0.0, float(rng.choice([10e-12, 50e-12, 300e-12])), tiles)
+        tol = float(rng.choice([1e-6, 1e-7]))
+        nopair = bool(rng.random() < 0.4)
+        e = E(dff_array(tiles, skew=skew, observe="q"))
+        kw = dict(abstol=tol, reltol=tol, saveat=sv, dc=dc_opts(abstol=1e-14))
+        if nopair:
+            os.environ["CEDARHIP_PERSIST_NOPAIR"] = "1"
+        try:
+            rc, t1, v1, _, st1 = e.tran(0.0, 4.2e-7, tran_opts(**kw))
+            os.environ["CEDARHIP_LOCKSTEP"] = "1"
+            rc2, t2, v2, _, st2 = e.tran(0.0, 4.2e-7, tran_opts(**kw))
+        finally:
+            os.environ.pop("CEDARHIP_LOCKSTEP", None)
+            os.environ.pop("CEDARHIP_PERSIST_NOPAIR", None)
+        tag = (trial, tiles, tol, nopair)
+        assert rc == 0 and rc2 == 0 and st1["stepper_mode"] == 2 and st2["stepper_mode"] in (0, 1), tag
+        assert np.max(np.abs(v1 - v2)) < 60 * tol * 5.0, (tag, np.max(np.abs(v1 - v2)))
+
+
 def test_row_buffer_drain_and_resume(E):
     """Without saveat every accepted step is a row; when the device row buffer fills, the kernel stops with its controller state
     and history written back and the host relaunches it (resume): the result must not depend on where the cuts fall."""
