@@ -276,11 +276,18 @@ def main():
                 rc_s, t_s, v_s, _, st_s = es.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts_s)
                 el_s = time.perf_counter() - t0s
                 qs = np.array([[np.interp(tt, t_s, v_s[k, :, 0]) for tt in DFF_CHECK_TIMES] for k in range(v_s.shape[0])])
+                # for comparison, ONE run with every accepted step of ONE step sequence saved (what a caller without saveat gets):
+                # 1024 private clocks are more than the device-resident controller's 64 lock-step sources, so this is the host stepper
+                t0l = time.perf_counter()
+                rc_l, t_l, v_l, _, st_l = es.tran(DFF_TSPAN[0], DFF_TSPAN[1], opts)
+                el_l = time.perf_counter() - t0l
                 line["skewed_clock_variant"] = {"workload": "same array, per-tile clock skew U(0,50 ps) seed 1234 (%d private clock sources)" % args.tiles,
                                                 "rc": rc_s, "ms_per_transient": 1e3 * el_s, "newton_iters_per_sec": st_s["nnonliniter"] / el_s,
                                                 "accepted_steps": st_s["naccept"], "rejected_steps": st_s["nreject"], "step_attempts": st_s["n_step_attempts"],
                                                 "step_controller": "device-resident, per-block step acceptance on the saveat grid of the gate times" if st_s["stepper"] == 2 else "host, lock-step",
                                                 "block_iterations": st_s["n_block_iters"],
+                                                "lockstep_every_step_saved": {"rc": rc_l, "ms_per_transient": 1e3 * el_l, "accepted_steps": st_l["naccept"], "rejected_steps": st_l["nreject"],
+                                                                              "block_iterations": st_l["n_block_iters"], "step_controller": "device-resident" if st_l["stepper"] == 2 else "host"},
                                                 "every_tile_meets_reference_gate": bool(np.max(np.abs(qs - np.array(DFF_CHECK_Q)[None, :])) <= 10 * TOL)}
             except Exception as ex:  # noqa: BLE001
                 line["skewed_clock_variant"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
