@@ -1250,6 +1250,7 @@ struct ch_circuit {
     pa.out_times = d_ptimes.p; pa.out_rows = d_prows.p; pa.max_rows = max_rows; pa.n_obs = n_obs;
     pa.ctl = d_pctl.p; pa.wg_rec = d_wgrec.p; pa.grp_rec = d_grprec.p; pa.counters = d_pcnt.p;
     pa.spin_ticks = 200000000LL;   // 2 s at 100 MHz
+    if (const char* sp = std::getenv("CEDARHIP_SPIN_TICKS")) pa.spin_ticks = std::max(1LL, std::atoll(sp));   // test hook: makes every wait give up (exercises the fallback)
     // a batch of single-block samples on a common output grid: every sample its own step sequence (no lock-step, no grid reduction)
     pa.indep = own_steps ? 1 : 0;
     persist_mode = A.nb > 0 ? CH_MODE_BORDERED : (own_steps ? CH_MODE_OWN_STEPS : CH_MODE_LOCKSTEP);
@@ -1458,6 +1459,7 @@ struct ch_circuit {
       }
     }
     auto tstart = hclock::now();
+    R.times.clear(); R.values.clear(); R.final_state.clear();   // (a launch that gave up may have left the rows of its first attempt)
     std::memset(&R.stats, 0, sizeof(R.stats));
     R.S = S; R.n_obs = (int)obs_kind.size();
     device_ms = 0; n_launch = 0; n_timed = 0;

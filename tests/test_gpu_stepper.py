@@ -279,3 +279,33 @@ def test_two_processes_share_the_gpu(tmp_path):
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0 and "SHARED_GPU_OK" in so, so[-1500:] + se[-1500:]
+
+
+def test_a_launch_that_gives_up_is_repeated_on_the_other_path(E):
+    """CEDARHIP_SPIN_TICKS=1 makes every grid-wide wait of the device-resident stepper run into its bound at once — what happens
+    when another process's kernel keeps part of the GPU and the cooperative launch is not co-resident.  The solve must come back
+    correct from the host stepper (independent blocks) or from the sparse path (a torn coupled array)."""
+    sv = np.linspace(0.0, 3e-7, 61)
+    kw = dict(abstol=1e-5, reltol=1e-5, saveat=sv, dc=dc_opts(abstol=1e-12))
+    for ckt in (dff_array(8, observe="q"), dff_array(9, observe="q", supply_r=1.0)):
+        e = E(ckt)
+        os.environ["CEDARHIP_LOCKSTEP"] = "1"       # the lock-step form has the grid-wide waits
+        try:
+            rc, t, v, _, st = e.tran(0.0, 3e-7, tran_opts(**kw))
+            os.environ["CEDARHIP_SPIN_TICKS"] = "1"
+            rc2, t2, v2, _, st2 = e.tran(0.0, 3e-7, tran_opts(**kw))
+        finally:
+            os.environ.pop("CEDARHIP_SPIN_TICKS", None)
+            os.environ.pop("CEDARHIP_LOCKSTEP", None)
+        assert rc == 0 and st["stepper"] == 2
+        assert rc2 == 0 and st2["stepper"] == 1, (rc2, st2["stepper"], e.ctx.last_error())
+        assert np.max(np.abs(v - v2)) < 1e-3
+    e = E(dff_array(8, observe="q"))
+    os.environ["CEDARHIP_SPIN_TICKS"] = "1"
+    os.environ["CEDARHIP_LOCKSTEP"] = "1"
+    try:
+        rc3, _, _, _, _ = e.tran(0.0, 3e-7, tran_opts(stepper="device", **kw))   # asked for explicitly: the error is reported
+    finally:
+        os.environ.pop("CEDARHIP_SPIN_TICKS", None)
+        os.environ.pop("CEDARHIP_LOCKSTEP", None)
+    assert rc3 == -5 and "wait exceeded its bound" in e.ctx.last_error()
