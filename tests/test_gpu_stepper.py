@@ -309,3 +309,23 @@ def test_a_launch_that_gives_up_is_repeated_on_the_other_path(E):
         os.environ.pop("CEDARHIP_SPIN_TICKS", None)
         os.environ.pop("CEDARHIP_LOCKSTEP", None)
     assert rc3 == -5 and "wait exceeded its bound" in e.ctx.last_error()
+
+
+def test_blocks_with_too_many_private_sources_keep_the_host_stepper(E):
+    """Eight RC blocks, each summing twenty private pulse sources: a workgroup of four blocks would need 80 source entries (the
+    device stepper holds 64 per workgroup), so the solve stays on the host stepper — and is right (superposition closed form at
+    the end of the plateau)."""
+    c = Circuit()
+    nsrc, r, cap = 20, 1e3, 1e-12
+    for b in range(8):
+        for k in range(nsrc):
+            c.V("v%d_%d" % (b, k), "s%d_%d" % (b, k), 0, dc=0.0, tran=PULSE(0.0, 0.1 * (k + 1), 1e-9 * (1 + b), 1e-9, 1e-9, 4e-7, 1e-6))
+            c.R("r%d_%d" % (b, k), "s%d_%d" % (b, k), "n%d" % b, r)
+        c.C("c%d" % b, "n%d" % b, 0, cap)
+        c.observe_node("n%d" % b)
+    e = E(c)
+    sv = np.linspace(0.0, 2e-7, 41)
+    rc, t, v, _, st = e.tran(0.0, 2e-7, tran_opts(abstol=1e-9, reltol=1e-7, saveat=sv))
+    assert rc == 0 and st["stepper"] == 1, (rc, st["stepper"], e.ctx.last_error())
+    want = np.mean([0.1 * (k + 1) for k in range(nsrc)])       # all sources on their plateau, the node settled (tau = r c / nsrc = 50 ps)
+    assert np.max(np.abs(v[:, -1, 0] - want)) < 1e-6
