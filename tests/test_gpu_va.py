@@ -355,3 +355,32 @@ def test_switch_branch_on_the_gpu(E):
         c.R("rl", "out", 0, 1e3)
         rc, x, status, st = E(c).dc(dc_opts(abstol=1e-15))
         assert rc == 0 and x[0][c._n("out") - 1] == pytest.approx(want, rel=1e-9)
+
+
+def test_temperature_sweep_of_a_compiled_device_as_samples(E):
+    """CH_SLOT_TEMP over the samples of one batch with a compiled Verilog-A device: every sample has its own constant block
+    (`va_setup_kernel` per sample: vt = $vt depends on the temperature) — against one-sample solves at each temperature."""
+    temps = [-20.0, 27.0, 100.0]
+
+    def ckt(temp=27.0):
+        c = Circuit(gmin=1e-12)
+        c.temp = temp
+        c.V("v1", "in", 0, dc=0.9)
+        c.R("r1", "in", "a", 100.0)
+        c.VA("d1", "va_diode", ["a", 0], {"IS": 1e-13, "RS": 2.0, "N": 1.2})
+        c.observe_node("a")
+        return c
+    c = ckt()
+    slot = c.slot("temp")
+    e = E(c)
+    e.set_samples(len(temps))
+    e.set_params([slot], [np.array(temps)])
+    rc, x, status, st = e.dc(dc_opts(abstol=1e-13))
+    assert rc == 0
+    nu, _, _ = e.maps()
+    va = [x[k][c._n("a") - 1] for k in range(len(temps))]
+    assert va[0] < va[1] < va[2]                       # no IS(T) in this model: the drop n vt ln(i / IS) grows with the temperature
+    for k, T in enumerate(temps):
+        c1 = ckt(T)
+        rc1, x1, _, _ = E(c1).dc(dc_opts(abstol=1e-13))
+        assert rc1 == 0 and abs(x1[0][c1._n("a") - 1] - va[k]) < 1e-9, (T, x1[0][c1._n("a") - 1], va[k])
