@@ -239,3 +239,17 @@ def test_bordered_operating_point(E, tiles, supply_r):
     assert np.max(np.abs(v[:, 0, 0] - v2[:, 0, 0])) < 1e-8, np.max(np.abs(v[:, 0, 0] - v2[:, 0, 0]))   # the same operating point (the same latch states)
     assert np.max(np.abs(v - v2)) < 1e-5
     assert st["dc_seconds"] < st2["dc_seconds"]
+
+
+def test_bordered_operating_point_from_a_given_start(E):
+    """`dc.x0` given (a previous operating point): the bordered solve starts there, finds it converged at once, and the transient
+    is the one of the cold start."""
+    e = E(coupled(10, 1.0))
+    sv = np.linspace(0.0, 2e-7, 41)
+    rc, x, status, st0 = e.dc(dc_opts(abstol=1e-12))           # the untorn circuit's (sparse path) operating point
+    assert rc == 0
+    rc1, t1, v1, _, st1 = e.tran(0.0, 2e-7, tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, dc=dc_opts(abstol=1e-12)))
+    rc2, t2, v2, _, st2 = e.tran(0.0, 2e-7, tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, dc=dc_opts(abstol=1e-10, x0=np.nan_to_num(x, nan=0.0))))
+    assert rc1 == 0 and rc2 == 0 and st1["stepper_mode"] == 3 and st2["stepper_mode"] == 3
+    assert np.max(np.abs(v1[:, 0, 0] - v2[:, 0, 0])) < 1e-8 and np.max(np.abs(v1 - v2)) < 1e-5
+    assert st2["nnonliniter"] < st1["nnonliniter"]              # no Newton iterations spent on the operating point
