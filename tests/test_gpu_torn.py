@@ -253,3 +253,6 @@ def test_bordered_operating_point_from_a_given_start(E):
     assert rc1 == 0 and rc2 == 0 and st1["stepper_mode"] == 3 and st2["stepper_mode"] == 3
     assert np.max(np.abs(v1[:, 0, 0] - v2[:, 0, 0])) < 1e-8 and np.max(np.abs(v1 - v2)) < 1e-5
     assert st2["nnonliniter"] < st1["nnonliniter"]              # no Newton iterations spent on the operating point
+    # the same state handed over with skip_dc: no operating-point solve at all (what __graft_entry__.smoke() does on a plain circuit)
+    rc3, t3, v3, _, st3 = e.tran(0.0, 2e-7, tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, skip_dc=True, dc=dc_opts(x0=np.nan_to_num(x, nan=0.0))))
+    assert rc3 == 0 and st3["stepper_mode"] == 3 and np.max(np.abs(v3 - v1)) < 1e-5
