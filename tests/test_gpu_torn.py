@@ -256,3 +256,26 @@ def test_bordered_operating_point_from_a_given_start(E):
     # the same state handed over with skip_dc: no operating-point solve at all (what __graft_entry__.smoke() does on a plain circuit)
     rc3, t3, v3, _, st3 = e.tran(0.0, 2e-7, tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, skip_dc=True, dc=dc_opts(x0=np.nan_to_num(x, nan=0.0))))
     assert rc3 == 0 and st3["stepper_mode"] == 3 and np.max(np.abs(v3 - v1)) < 1e-5
+
+
+def test_parameter_overrides_reach_the_torn_form(E):
+    """ch_set_params on the circuit is forwarded to its torn companion: a new value of the rail resistor (a device that sits on the
+    border alone and is stamped by every wavefront from the host's table) changes the droop, and both paths see the same value."""
+    ckt = coupled(10, 1.0)
+    slot = ckt.slot("rvdd", "r")
+    e = E(ckt)
+    sv = np.linspace(0.0, 1.2e-7, 25)
+    opts = tran_opts(abstol=1e-6, reltol=1e-6, saveat=sv, dc=dc_opts(abstol=1e-12))
+    rc, t, v1, _, st = e.tran(0.0, 1.2e-7, opts)
+    e.set_samples(1)
+    e.set_params([slot], [np.array([25.0])])
+    rc2, t2, v2, _, st2 = e.tran(0.0, 1.2e-7, opts)
+    os.environ["CEDARHIP_NO_TEAR"] = "1"
+    try:
+        rc3, t3, v3, _, st3 = e.tran(0.0, 1.2e-7, opts)
+    finally:
+        del os.environ["CEDARHIP_NO_TEAR"]
+    assert rc == 0 and rc2 == 0 and rc3 == 0 and st2["stepper_mode"] == 3 and st3["stepper"] == 1
+    assert np.max(np.abs(v2 - v3)) < 1e-5
+    droop1, droop2 = 5.0 - np.min(v1[-2]), 5.0 - np.min(v2[-2])
+    assert droop2 > 5.0 * droop1 > 0.0, (droop1, droop2)       # 25 ohm instead of 1 ohm
