@@ -329,3 +329,19 @@ def test_blocks_with_too_many_private_sources_keep_the_host_stepper(E):
     assert rc == 0 and st["stepper"] == 1, (rc, st["stepper"], e.ctx.last_error())
     want = np.mean([0.1 * (k + 1) for k in range(nsrc)])       # all sources on their plateau, the node settled (tau = r c / nsrc = 50 ps)
     assert np.max(np.abs(v[:, -1, 0] - want)) < 1e-6
+
+
+def test_return_codes_of_both_step_controllers(E):
+    """The SciML return codes the binding maps: MaxIters when the step budget runs out, DtLessThanMin when the step
+    size underflows, on the host stepper, the lock-step device stepper and the own-steps device stepper alike; partial results
+    come back with the rows reached so far."""
+    e = E(dff_array(4, observe="q"))
+    sv = np.linspace(0.0, 7e-7, 71)
+    for stepper, extra, mode in (("host", {}, 0), ("device", {}, 1), ("device", {"saveat": sv}, 2)):
+        rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, stepper=stepper, max_steps=40, dc=dc_opts(abstol=1e-14), **extra))
+        assert rc == -7 and st["stepper_mode"] == mode, (stepper, extra.keys(), rc, st["stepper_mode"])       # MaxIters
+        assert st["naccept"] <= 40 and (len(t) == 0 or t[-1] < DFF_TSPAN[1])
+        rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, stepper=stepper, dtmin=1e-9, dc=dc_opts(abstol=1e-14), **extra))
+        assert rc == -4 and st["stepper_mode"] == mode, (stepper, extra.keys(), rc)                             # DtLessThanMin: the 1 ns edges need smaller steps
+    rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14)))
+    assert rc == 0          # and the circuit is fine afterwards
