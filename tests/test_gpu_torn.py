@@ -279,3 +279,13 @@ def test_parameter_overrides_reach_the_torn_form(E):
     assert np.max(np.abs(v2 - v3)) < 1e-5
     droop1, droop2 = 5.0 - np.min(v1[-2]), 5.0 - np.min(v2[-2])
     assert droop2 > 5.0 * droop1 > 0.0, (droop1, droop2)       # 25 ohm instead of 1 ohm
+
+
+def test_return_codes_of_the_bordered_form(E):
+    e = E(coupled(9, 1.0))
+    rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, max_steps=30, dc=dc_opts(abstol=1e-12)))
+    assert rc == -7 and st["stepper_mode"] == 3 and st["naccept"] <= 30          # MaxIters, from the bordered form itself
+    rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, dtmin=1e-9, dc=dc_opts(abstol=1e-12)))
+    assert rc == -4 and st["stepper_mode"] == 3                                    # DtLessThanMin
+    rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-12)))
+    assert rc == 0 and t[-1] == DFF_TSPAN[1]
