@@ -192,8 +192,10 @@ typedef struct ch_tran_opts {
   double dt0;        /* initial step, 0 = auto */
   int32_t max_steps; /* 0 = 10 000 000 */
   int32_t newton_maxiters; /* default 10 */
-  int32_t n_saveat;        /* 0: save every accepted step */
-  const double* saveat;    /* [n_saveat] increasing times to save (dense output by interpolation) */
+  int32_t n_saveat;        /* 0: save every accepted step (ONE step sequence and time vector for the whole circuit / batch) */
+  const double* saveat;    /* [n_saveat] increasing times to save (dense output by interpolation).  With a saveat grid the samples of a batch,
+                              and the structurally independent blocks of one circuit, may each take their own step sequence (what
+                              sol(t) of separate solves would give; error control per sample / block) */
   ch_dc_opts dc;           /* initialisation (CedarDCOp) */
   int32_t skip_dc;         /* 1: start from dc.x0 as given (u0 passed by the caller, test/common.jl:36-43) */
   int32_t stepper;         /* CH_STEPPER_AUTO (default): device-resident controller where the circuit qualifies, host otherwise;
