@@ -362,58 +362,61 @@ class CircuitSweep:
     def _batch(self, lo, hi):
         """Base circuit + slots + per-sample values for points lo..hi, found by diffing the flat tables of built circuits.
 
-        The reference rebuilds nothing per point: `remake(prob, p=sim)` swaps a parameter struct (src/sweeps.jl:473-480).  Here
-        the netlist is rebuilt only as often as needed to learn the parameter -> table map: for a sweep whose variables act on
-        DISJOINT table entries (a product sweep over two resistors, a model parameter and a supply …) one build per distinct
-        value of each variable (sum of the axis lengths) instead of one per point (their product); the per-point tables are
-        then assembled by look-up.  Anything else (an entry that depends on two swept variables, zipped variables with as many
-        distinct values as points) takes one build per point."""
+        The reference rebuilds nothing per point: `remake(prob, p=sim)` swaps a parameter struct (src/sweeps.jl:278-290,
+        473-480).  Here the netlist is rebuilt only as often as needed to LEARN the swept-name -> table-entry map:
+          * a variable with at most four distinct values: one build per value (exact look-up);
+          * any other variable (the Monte-Carlo shape: a TandemSweep with as many distinct values as points): three builds —
+            two determine an identity / proportional / affine map for every entry the variable moves, the third checks it;
+          * the assembled table is then VALIDATED against full builds of the point with the most variables away from the
+            base point and of a few seeded random points: an entry that answers to two variables (r = a*b with a base of
+            a = 0, a conditional) is not visible from single-axis builds around one point.
+        Any failed check (an entry moved by two variables, a non-affine map, a validation mismatch) falls back to one build
+        per point, which is always correct.  `self.setup` records what was done (builds, seconds, which way)."""
+        import time
         from .circuit import SLOT_SRC_DC, SLOT_SRC_PAR
+        t_setup = time.perf_counter()
         pts = self.points[lo:hi]
         base = self._build(**pts[0])
         v0, keys = self._flat(base)
         differs = lambda x, y: (x != y) & ~(np.isnan(x) & np.isnan(y))  # noqa: E731
-        table = None
+        n_builds = [1]
+
+        def flat_of(point):
+            c = self._build(**point)
+            n_builds[0] += 1
+            self._same_topology(base, c)
+            vv, _ = self._flat(c)
+            if len(vv) != len(v0):
+                raise CedarError("sweep points must not change the circuit topology")
+            return vv
+
+        def close(x, y):
+            return np.all((x == y) | (np.isnan(x) & np.isnan(y)) | (np.abs(x - y) <= 1e-13 * np.maximum(np.abs(x), np.abs(y))))
+
+        table, how = None, "one build per point"
         names = sorted({k for p in pts for k in p})
-        if names and all(set(p) == set(names) for p in pts):
+        numeric = lambda v: isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool)  # noqa: E731
+        if names and len(pts) > 1 and all(set(p) == set(names) for p in pts):
             distinct = {k: list(dict.fromkeys(p[k] for p in pts)) for k in names}
-            if 1 + sum(len(v) - 1 for v in distinct.values()) < len(pts):
-                cols, owner, ok = {}, np.full(len(v0), -1), True
-                for ki, k in enumerate(names):
-                    for val in distinct[k]:
-                        if val == pts[0][k]:
-                            cols[(k, val)] = v0
-                            continue
-                        c = self._build(**dict(pts[0], **{k: val}))
-                        self._same_topology(base, c)
-                        vv, _ = self._flat(c)
-                        if len(vv) != len(v0):
-                            ok = False
+            n_check = min(4, len(pts) - 1)
+            cost = 1 + sum(min(len(v) - 1, 2) if all(numeric(x) for x in v) else len(v) - 1 for v in distinct.values()) + n_check
+            if cost < len(pts):
+                table = self._learn_table(pts, names, distinct, v0, flat_of, differs, close, numeric)
+                if table is not None:
+                    # validation: the point farthest from the base point (most variables changed) + seeded random points
+                    far = max(range(1, len(pts)), key=lambda r: sum(pts[r][k] != pts[0][k] for k in names))
+                    rng = np.random.default_rng(len(pts))
+                    picks = {far, len(pts) - 1} | {int(r) for r in rng.integers(1, len(pts), size=max(0, n_check - 2))}
+                    for r in sorted(picks):
+                        if not close(flat_of(pts[r]), table[r]):
+                            table = None   # e.g. an entry that depends on two swept variables
                             break
-                        ch = differs(vv, v0)
-                        if np.any(ch & (owner >= 0) & (owner != ki)):
-                            ok = False   # an entry that answers to two variables: not separable
-                            break
-                        owner[ch] = ki
-                        cols[(k, val)] = vv
-                    if not ok:
-                        break
-                if ok:
-                    table = np.tile(v0, (len(pts), 1))
-                    for ki, k in enumerate(names):
-                        idx = np.nonzero(owner == ki)[0]
-                        if len(idx):
-                            for r, p in enumerate(pts):
-                                table[r, idx] = cols[(k, p[k])][idx]
+                if table is not None:
+                    how = "learned map (%d builds for %d points)" % (n_builds[0], len(pts))
         if table is None:
             rows = [v0]
             for p in pts[1:]:
-                c = self._build(**p)
-                self._same_topology(base, c)
-                vv, _ = self._flat(c)
-                if len(vv) != len(v0):
-                    raise CedarError("sweep points must not change the circuit topology")
-                rows.append(vv)
+                rows.append(flat_of(p))
             table = np.array(rows)
         ch = np.nonzero(np.any(differs(table, table[0:1]), axis=0))[0]
         slots = [keys[i] for i in ch]
@@ -423,7 +426,71 @@ class CircuitSweep:
         slots = [keys[i] for i in ch]
         base.slots = list(slots)
         base.slot_names = [("slot%d" % i, None) for i in range(len(slots))]
+        self.setup = {"points": len(pts), "circuit_builds": n_builds[0], "seconds": time.perf_counter() - t_setup, "how": how, "slots": len(slots)}
         return base, list(range(len(slots))), np.ascontiguousarray(table[:, ch].T, float).reshape(len(slots), hi - lo)
+
+    @staticmethod
+    def _learn_table(pts, names, distinct, v0, flat_of, differs, close, numeric):
+        """Per-point flat tables from single-axis builds around pts[0]; None when the sweep is not separable that way."""
+        owner = np.full(len(v0), -1)
+        table = np.tile(v0, (len(pts), 1))
+        for ki, k in enumerate(names):
+            vals = distinct[k]
+            x0 = pts[0][k]
+            others = [v for v in vals if v != x0]
+            if not others:
+                continue
+            cols = {x0: v0}
+
+            def lookup():
+                moved = np.zeros(len(v0), bool)
+                for val in others:
+                    if val not in cols:
+                        cols[val] = flat_of(dict(pts[0], **{k: val}))
+                    moved |= differs(cols[val], v0)
+                if np.any(moved & (owner >= 0) & (owner != ki)):
+                    return False
+                owner[moved] = ki
+                idx = np.nonzero(moved)[0]
+                for r, p in enumerate(pts):
+                    table[r, idx] = cols[p[k]][idx]
+                return True
+
+            if len(others) <= 3 or not all(numeric(v) for v in vals):
+                if not lookup():
+                    return None
+                continue
+            # many distinct numeric values: every entry the variable moves must be an affine function of it
+            x1 = max(others, key=lambda v: abs(v - x0))
+            x2 = min((v for v in others if v != x1), key=lambda v: abs(v - 0.5 * (x0 + x1)))
+            v1, v2 = flat_of(dict(pts[0], **{k: x1})), flat_of(dict(pts[0], **{k: x2}))
+            cols[x1], cols[x2] = v1, v2
+            moved = differs(v1, v0) | differs(v2, v0)
+            if np.any(moved & (owner >= 0)):
+                return None
+            idx = np.nonzero(moved)[0]
+            if not len(idx):
+                continue
+            xs = np.array([float(p[k]) for p in pts])
+            a0, a1, a2 = v0[idx], v1[idx], v2[idx]
+            ident = (a0 == x0) & (a1 == x1) & (a2 == x2)
+            with np.errstate(all="ignore"):
+                cprop = a1 / x1 if x1 != 0 else np.full(len(idx), np.nan)
+                prop = ~ident & (cprop * x0 == a0) & (cprop * x2 == a2)
+                slope = (a1 - a0) / (float(x1) - float(x0))
+                pred2 = a0 + slope * (float(x2) - float(x0))
+            if not close(np.where(ident | prop, a2, pred2), a2):
+                # not affine in the swept variable (1/x, x^2, a table look-up ...): one build per distinct value, if that is
+                # still cheaper than one per point
+                if 2 * len(vals) < len(pts) and lookup():
+                    continue
+                return None
+            owner[moved] = ki
+            col = a0[None, :] + slope[None, :] * (xs[:, None] - float(x0))
+            col = np.where(prop[None, :], cprop[None, :] * xs[:, None], col)   # the builder's own product, bit for bit
+            col = np.where(ident[None, :], xs[:, None], col)
+            table[:, idx] = col
+        return table
 
     def _run(self, kind, kw, ctx):
         lo, hi = shard_range(len(self.points), self.rank, self.world)

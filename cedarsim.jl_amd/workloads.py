@@ -200,6 +200,51 @@ def mc_samples(n_samples, seed=2024, sigma=0.03):
     return {k: 1.0 + sigma * rng.standard_normal(n_samples) for k in ("n.vth0", "n.u0", "n.toxe", "p.vth0", "p.u0", "p.toxe")}
 
 
+MC_NAMES = ("n_vth0", "n_u0", "n_toxe", "p_vth0", "p_u0", "p_toxe", "dw", "dl")
+
+
+def dff_mc_builder(gmin=1e-15):
+    """Config 4 as the reference would see it: a circuit BUILDER whose keyword arguments are the swept names of an explicit
+    `TandemSweep` (src/sweeps.jl:278-290) — multipliers on vth0 / u0 / toxe of both cards (N(1, 0.03)) and global W / L
+    deltas in metres (N(0, 5 nm)), SURVEY 8(d) config 4.  Returns (build(**point) -> Circuit of one DFF, names)."""
+    cards = gf180_models()
+
+    def build(**kw):
+        c = Circuit(gmin=gmin)
+        mi = {}
+        for typ, mname in (("n", "nfet_06v0"), ("p", "pfet_06v0")):
+            name, mtype, params = cards[mname]
+            pr = dict(params)
+            for par in ("vth0", "u0", "toxe"):
+                pr[par] = float(pr[par]) * float(kw.get("%s_%s" % (typ, par), 1.0))
+            mi[typ] = c.add_model(name, mtype, pr)
+        dw, dl = float(kw.get("dw", 0.0)), float(kw.get("dl", 0.0))
+        c.V("vvdd", "vdd", 0, dc=5.0)
+        c.V("vvss", "vss", 0, dc=0.0)
+        c.V("vnw", "vnw", "vdd", dc=0.0)
+        c.V("vpw", "vpw", "vss", dc=0.0)
+        c.V("vclkn", "clkn", 0, tran=PWL(CLKN_PWL))
+        c.V("vd", "d", 0, tran=PWL(D_PWL))
+        for name, d, g, s, b, typ, w in DFF_FETS:
+            c.M("x_" + name, d.lower(), g.lower(), s.lower(), b.lower(), mi[typ], w + dw, (LN if typ == "n" else LP) + dl)
+        c.C("cq", "q_tmp", 0, 1.7205e-13)
+        c.V("vq", "q", "q_tmp", dc=0.0)
+        c.observe_node("q")
+        return c
+
+    return build, MC_NAMES
+
+
+def mc_tandem_sweep(n_samples, seed=2024, sigma=0.03, sigma_wl=5e-9):
+    """The explicit TandemSweep of config 4 (seed 2024): one value of every MC_NAMES variable per sample."""
+    from .sweeps import TandemSweep
+    rng = np.random.default_rng(seed)
+    cols = {}
+    for k in MC_NAMES:
+        cols[k] = list(sigma_wl * rng.standard_normal(n_samples)) if k in ("dw", "dl") else list(1.0 + sigma * rng.standard_normal(n_samples))
+    return TandemSweep(**cols)
+
+
 CMG_INVERTER_DECK = """* BSIM-CMG inverter array (test/bsimcmg/inverter_cmg_cedar.cir:6-14, tiled)
 VVDD VDD 0 1.0
 VVSS VSS 0 0.0

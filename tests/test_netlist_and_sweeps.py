@@ -174,9 +174,9 @@ def test_solution_call_interpolates_with_pchip():
 
 def test_sweep_batch_learns_the_parameter_map_from_few_builds():
     """CircuitSweep._batch (the host half of `remake(prob, p=sim)` over a sweep, src/sweeps.jl:471-482): a product sweep whose
-    variables act on disjoint table entries is assembled from one build per distinct axis value (20 + 20 - 1 = 39 builds for
-    the reference's 400-point sweep, test/sweep.jl:326-340), a sweep with a coupled entry falls back to one build per point,
-    and both give the per-point tables exactly."""
+    variables act on disjoint table entries is assembled from a handful of builds (the base point, two per axis for the
+    identity / affine map, up to four validation points: at most 9 for the reference's 400-point sweep, test/sweep.jl:326-340),
+    a sweep with a coupled entry falls back to one build per point, and both give the per-point tables exactly."""
     import numpy as np
     from cedarsim_jl_amd import Circuit, CircuitSweep, ProductSweep, TandemSweep, frange
     count = {"n": 0}
@@ -191,7 +191,7 @@ def test_sweep_batch_learns_the_parameter_map_from_few_builds():
 
     cs = CircuitSweep(two_resistor, ProductSweep(R1=frange(100.0, 100.0, 2000.0), R2=frange(100.0, 100.0, 2000.0)))
     base, ids, vals = cs._batch(0, 400)
-    assert count["n"] == 39 and vals.shape == (2, 400) and len(base.slots) == 2
+    assert count["n"] <= 9 and vals.shape == (2, 400) and len(base.slots) == 2 and cs.setup["circuit_builds"] == count["n"]
     r1 = [p["R1"] for p in cs]
     r2 = [p["R2"] for p in cs]
     by_slot = {s[1]: vals[i] for i, s in enumerate(base.slots)}
@@ -213,3 +213,53 @@ def test_sweep_batch_learns_the_parameter_map_from_few_builds():
     cs3 = CircuitSweep(two_resistor, TandemSweep(R1=[1.0, 2.0, 3.0], R2=[4.0, 5.0, 6.0]))   # zipped: as many values as points
     base3, _, vals3 = cs3._batch(0, 3)
     assert count["n"] == 3 and vals3.shape == (2, 3)
+
+
+def test_sweep_batch_is_validated_against_full_builds():
+    """a dependence that vanishes at the base point is invisible to single-axis builds around it —
+    R = 1e3 + a*b with a base of a = 0, or a conditional.  The assembled table is checked against full builds of the far
+    corner and of seeded random points, and any mismatch falls back to one build per point."""
+    from cedarsim_jl_amd import Circuit, CircuitSweep
+
+    def make(f):
+        def build(**kw):
+            c = Circuit()
+            c.V("V", "vcc", 0, dc=1.0)
+            c.R("R", "vcc", 0, f(**kw))
+            return c
+        return build
+
+    cs = CircuitSweep(make(lambda a=0.0, b=1.0: 1e3 + a * b), ProductSweep(a=[0.0, 1.0, 2.0], b=[1.0, 2.0, 3.0]))
+    _, _, vals = cs._batch(0, 9)
+    assert np.array_equal(vals[0], [1e3 + p["a"] * p["b"] for p in cs]) and cs.setup["how"] == "one build per point"
+    # conditional: the entry follows `a` only in mode 1, and the base point is in mode 0
+    cs = CircuitSweep(make(lambda mode=0, a=1.0: (a if mode else 50.0)), ProductSweep(mode=[0, 1], a=[1.0, 2.0, 3.0, 4.0, 5.0, 6.0]))
+    _, _, vals = cs._batch(0, 12)
+    assert np.array_equal(vals[0], [(p["a"] if p["mode"] else 50.0) for p in cs])
+    # a map that is not affine in its variable (1/g): one build per distinct value, still exact
+    gs = [1e-3 * (i + 1) for i in range(12)]
+    cs = CircuitSweep(make(lambda g=1e-3, k=1.0: 1.0 / g), ProductSweep(g=gs, k=[1.0, 2.0, 3.0, 4.0, 5.0, 6.0]))
+    _, _, vals = cs._batch(0, 72)
+    assert np.array_equal(vals[0], [1.0 / p["g"] for p in cs]) and cs.setup["circuit_builds"] < 72
+
+
+def test_monte_carlo_tandem_sweep_needs_a_handful_of_builds():
+    """process-variation samples enter as an explicit TandemSweep (src/sweeps.jl:278-290) with as many
+    distinct values as points.  The name -> table-entry map is learned from three builds per variable (identity /
+    proportional / affine), not one per point; the table equals the per-point builds bit for bit."""
+    from cedarsim_jl_amd import CircuitSweep
+    from cedarsim_jl_amd import bsim4_params as B4
+    from cedarsim_jl_amd.workloads import dff_mc_builder, mc_tandem_sweep
+    S = 256
+    build, names = dff_mc_builder()
+    cs = CircuitSweep(build, mc_tandem_sweep(S))
+    base, ids, vals = cs._batch(0, S)
+    assert cs.setup["circuit_builds"] <= 1 + 2 * len(names) + 4 and vals.shape[1] == S and cs.setup["how"].startswith("learned")
+    assert len(base.slots) == 6 + 2 * 30   # six card entries, W and L of the thirty MOSFETs
+    for r in (1, 17, 200, S - 1):   # against the per-point build
+        c = build(**cs.points[r])
+        for i, sl in enumerate(base.slots):
+            if sl[0] == 2:     # SLOT_MODEL_PAR: proportional map, the builder's own product
+                assert vals[i, r] == c.models[sl[1]][sl[2]]
+            else:              # SLOT_DEV_PAR (W + dw, L + dl): affine map, equal to rounding
+                assert sl[0] == 1 and abs(vals[i, r] - c.dev_par[sl[1]][sl[2]]) <= 1e-13 * abs(vals[i, r])
