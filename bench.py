@@ -14,6 +14,13 @@ check times and the iteration counts are gathered once at the end over RCCL).
 
 value = Newton iterations (of the whole array, i.e. max over blocks per step attempt, summed over
 ranks) / wall seconds, with the circuit description already resident on the GPU.
+
+`--gpus N` means N: started WITHOUT a launcher (no WORLD_SIZE in the environment) and N > 1, this process starts the N ranks
+itself as a child (`python -m torch.distributed.run --nproc-per-node N bench.py ...`) before anything touches the GPU, relays
+rank 0's JSON line and exits with the child's code; started under a launcher whose WORLD_SIZE differs from --gpus it refuses.
+With N > 1 the line carries a second, separate measurement, `config4_sharded_sweep`: the 8192-sample-class Monte-Carlo sweep
+of SURVEY 8(d) config 4 at 1024 samples per rank through `CircuitSweep(rank, world)`, with the full result rows
+[samples x observables x save points] gathered by ONE all_gather over RCCL (last row).
 """
 import argparse
 import json
@@ -106,6 +113,119 @@ def combine_ranks(dist, world, device, iters, el, gate_ok, q):
     return float(res[:, 0].sum()), float(res[:, 1].max()), bool(res[:, 2].min() > 0.5), res[:, 3:].tolist()
 
 
+def launch_ranks(n, argv):
+    """Parent of a launcher-less `bench.py --gpus N` (N > 1): no torch.cuda / HIP call has happened in this process.  The ranks
+    run in a CHILD process tree (never exec: the GPU box forbids replacing a process that may have touched the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    relayed = 0
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            relayed += 1
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and relayed != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, saw %d\n" % relayed)
+        rc = 3
+    return rc
+
+
+def config4_sharded_sweep(ctx, rank, world, dist, backend, samples_per_rank=1024, n_save=2001, plumbing_only=False):
+    """an explicit Monte-Carlo TandemSweep of one DFF (src/sweeps.jl:278-290, 471-502), 1024 samples per
+    rank, sharded by `CircuitSweep(rank, world)` (contiguous blocks of points), every rank's share ONE batched solve on the
+    device-resident stepper with per-sample steps, output on a saveat grid; then the collective of the path: ONE all_gather of the
+    rows [samples, observables, save points] (RCCL over xGMI with the nccl backend).  Returns the rank-0 report."""
+    import numpy as np
+    import torch
+    from cedarsim_jl_amd import CircuitSweep, gather_sharded
+    from cedarsim_jl_amd.workloads import DFF_CHECK_Q, DFF_CHECK_TIMES, DFF_TSPAN, dff_mc_builder, mc_tandem_sweep
+    S_total = samples_per_rank * world
+    saveat = np.unique(np.concatenate((np.linspace(DFF_TSPAN[0], DFF_TSPAN[1], n_save), np.array(DFF_CHECK_TIMES))))
+    build, names = dff_mc_builder(observe=("q", "q_neg"))
+    cs = CircuitSweep(build, mc_tandem_sweep(S_total), rank=rank, world=world)
+    t0 = time.perf_counter()
+    if plumbing_only:   # CPU rehearsal of launcher + gather: rows are a pattern that encodes (sample, observable, save point)
+        from cedarsim_jl_amd.sweeps import shard_range
+        lo, hi = shard_range(S_total, rank, world)
+        rows = (np.arange(lo, hi)[:, None, None] * 1e3 + np.arange(2)[None, :, None] * 1e2 + np.arange(len(saveat))[None, None, :] * 1e-3)
+        stats, setup, rc = {"nnonliniter": 0, "dc_seconds": 0.0, "stepper": 0, "stepper_mode": 0}, {"circuit_builds": 0, "seconds": 0.0, "how": "plumbing only"}, 0
+    else:
+        rc, t, rows, stats = cs.tran_arrays(DFF_TSPAN, abstol=TOL, reltol=TOL, dc_abstol=1e-14, saveat=saveat, ctx=ctx)
+        setup = cs.setup
+    solve_s = time.perf_counter() - t0
+    dev = "cuda" if backend == "nccl" else "cpu"
+    if dist is not None:
+        dist.barrier()
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    full = gather_sharded(rows, S_total, rank, world, device=dev) if dist is not None else rows
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    gather_s = time.perf_counter() - t0
+    # every rank holds every sample's rows now: check the reference's gate on ALL of them, and that the shards landed in order
+    ci = np.searchsorted(saveat, np.array(DFF_CHECK_TIMES))
+    if plumbing_only:
+        want = (np.arange(S_total)[:, None, None] * 1e3 + np.arange(2)[None, :, None] * 1e2 + np.arange(len(saveat))[None, None, :] * 1e-3)
+        ok = bool(np.array_equal(full, want))
+        n_pass = S_total if ok else 0
+    else:
+        passed = np.all(np.abs(full[:, 0, :][:, ci] - np.array(DFF_CHECK_Q)[None, :]) <= 10 * TOL, axis=1)
+        n_pass = int(passed.sum())
+        lo = rank * samples_per_rank
+        ok = bool(np.array_equal(full[lo:lo + samples_per_rank], rows))
+    vec = [solve_s, gather_s, float(rc), float(stats["nnonliniter"]), float(ok), float(setup["seconds"])]
+    if dist is not None:
+        buf = torch.tensor(vec, dtype=torch.float64, device=dev)
+        out = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
+        res = torch.stack(out).cpu().numpy()
+    else:
+        res = np.array([vec])
+    bytes_per_rank = int(rows.size * 8)
+    return {"workload": "Monte-Carlo TandemSweep of one GF180 DFF (%s), %d samples per rank, %d in total, transient 0..700 ns abstol=reltol=1e-4, "
+                        "saveat grid of %d points, %d observables" % (", ".join(names), samples_per_rank, S_total, len(saveat), rows.shape[1]),
+            "samples_total": S_total, "samples_per_rank": samples_per_rank, "n_obs": int(rows.shape[1]), "n_save": int(rows.shape[2]),
+            "rc_worst": int(res[:, 2].min()), "solve_seconds_max_over_ranks": float(res[:, 0].max()), "sweep_setup_seconds_max_over_ranks": float(res[:, 5].max()),
+            "sweep_setup": setup, "newton_iters_total": float(res[:, 3].sum()), "samples_per_second": S_total / float(res[:, 0].max()),
+            "gather": {"collective": "one all_gather of [samples/rank, n_obs, n_save] fp64 rows (%s)" % ("RCCL over xGMI" if backend == "nccl" else backend),
+                       "bytes_per_rank": bytes_per_rank, "seconds_max_over_ranks": float(res[:, 1].max()),
+                       "GBps_per_rank_received": (world - 1) * bytes_per_rank / max(1e-12, float(res[:, 1].max())) / 1e9 if world > 1 else None,
+                       "includes": "host -> device staging of the rank's rows, the collective, device -> host of the gathered rows"},
+            "every_rank_sees_its_shard_in_place": bool(res[:, 4].min() > 0.5), "samples_passing_reference_gate": n_pass,
+            "stepper": "device-resident, per-sample step acceptance" if stats.get("stepper") == 2 else ("plumbing only" if plumbing_only else "host"),
+            "plumbing_only": bool(plumbing_only)}
+
+
+def plumbing_only_line(args, rank, world):
+    """`--plumbing-only` (hidden; tests/test_capi_and_dist.py): launcher, rendezvous, `combine_ranks` and the full-size config-4
+    gather over gloo on a machine without a GPU.  No engine, no oracle, no measurement: `value` is null."""
+    import torch.distributed as dist
+    d = None
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        d = dist
+    tot, mx, gate, allq = combine_ranks(d, world, "cpu", 1000 + rank, 0.05 + 0.01 * rank, True, [0.0, 0.0, 5.0, 5.0, 5.0])
+    c4 = config4_sharded_sweep(None, rank, world, d, "gloo", samples_per_rank=args.mc_samples_per_rank, plumbing_only=True)
+    if rank == 0:
+        print(json.dumps({"metric": "newton_iters_per_sec", "value": None, "unit": "newton_iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "plumbing_only": True, "combined_iters": tot, "slowest_rank_seconds": mx, "config4_sharded_sweep": c4}))
+    if d is not None:
+        d.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,13 +235,28 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-skew", action="store_true", help="skip the second, clearly labelled measurement with per-tile clock skew")
     ap.add_argument("--stepper", default="auto", choices=["auto", "host", "device"], help=argparse.SUPPRESS)
+    ap.add_argument("--mc-samples-per-rank", type=int, default=1024, help=argparse.SUPPRESS)
+    ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)   # CPU test of launcher + collectives: no engine, no `value`
     args = ap.parse_args()
+
+    # ---- --gpus N means N ----
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to report a line for the wrong job size\n"
+                         % (args.gpus, os.environ["WORLD_SIZE"]))
+        sys.exit(2)
 
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.plumbing_only:
+        return plumbing_only_line(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
     # CEDARHIP_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the result
@@ -202,6 +337,16 @@ def main():
     gate_ok = all(abs(a - b) <= 10 * TOL for a, b in zip(q, DFF_CHECK_Q))
 
     tot_iters, max_el, gate_ok, all_q = combine_ranks(dist, world, "cuda" if backend == "nccl" else "cpu", iters, el, gate_ok, q)
+
+    c4 = None
+    if world > 1:
+        # second, separate measurement (never `value`): the sharded Monte-Carlo sweep with its full-size result gather
+        try:
+            c4 = config4_sharded_sweep(ctx, rank, world, dist, backend, samples_per_rank=args.mc_samples_per_rank)
+        except Exception as ex:  # noqa: BLE001
+            if dist is not None and world > 1:
+                raise   # a rank that drops out of a collective would hang the others: fail the job loudly instead
+            c4 = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if rank == 0:
         nc, n_mos = info["max_component"], MOS_PER_TILE
@@ -315,6 +460,8 @@ def main():
                                                  "every_tile_meets_reference_gate": bool(np.max(np.abs(qc - np.array(DFF_CHECK_Q)[None, :])) <= 10 * TOL)}
             except Exception as ex:  # noqa: BLE001
                 line["coupled_rails_variant"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if c4 is not None:
+            line["config4_sharded_sweep"] = c4
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()

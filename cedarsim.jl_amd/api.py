@@ -548,6 +548,21 @@ class CircuitSweep:
             sol.circuit = self._sample_circuit(ckt, slot_ids, vals, s)
         return sols
 
+    def tran_arrays(self, tspan, abstol=1e-6, reltol=1e-3, dc_abstol=1e-10, saveat=None, ctx=None, **kw):
+        """This rank's share of the sweep as ONE batched transient, results as arrays instead of per-point Solutions: the shape
+        the result gather of a sharded sweep moves (`gather_sharded`).  Returns (rc, t[n_save],
+        rows[samples, n_obs, n_save], stats); observables in the order of `builder(...).obs`."""
+        lo, hi = shard_range(len(self.points), self.rank, self.world)
+        base, slot_ids, vals = self._batch(lo, hi)
+        ckt = _prepare(base, None)
+        eng = EngineCircuit(ckt, ctx)
+        eng.set_samples(hi - lo)
+        if slot_ids:
+            eng.set_params(slot_ids, vals)
+        opts = tran_opts(abstol=abstol, reltol=reltol, saveat=saveat, dc=dc_opts(abstol=dc_abstol), **kw)
+        rc, t, v, xf, st = eng.tran(tspan[0], tspan[1], opts)
+        return rc, t, np.ascontiguousarray(np.transpose(v, (2, 0, 1))), st
+
     @staticmethod
     def _sample_circuit(ckt, slot_ids, vals, s):
         """Shallow per-sample view so that post-processing (e.g. R.I = V/r) uses the sample's values."""

@@ -203,7 +203,7 @@ def mc_samples(n_samples, seed=2024, sigma=0.03):
 MC_NAMES = ("n_vth0", "n_u0", "n_toxe", "p_vth0", "p_u0", "p_toxe", "dw", "dl")
 
 
-def dff_mc_builder(gmin=1e-15):
+def dff_mc_builder(gmin=1e-15, observe=("q",)):
     """Config 4 as the reference would see it: a circuit BUILDER whose keyword arguments are the swept names of an explicit
     `TandemSweep` (src/sweeps.jl:278-290) — multipliers on vth0 / u0 / toxe of both cards (N(1, 0.03)) and global W / L
     deltas in metres (N(0, 5 nm)), SURVEY 8(d) config 4.  Returns (build(**point) -> Circuit of one DFF, names)."""
@@ -229,7 +229,8 @@ def dff_mc_builder(gmin=1e-15):
             c.M("x_" + name, d.lower(), g.lower(), s.lower(), b.lower(), mi[typ], w + dw, (LN if typ == "n" else LP) + dl)
         c.C("cq", "q_tmp", 0, 1.7205e-13)
         c.V("vq", "q", "q_tmp", dc=0.0)
-        c.observe_node("q")
+        for o in observe:
+            c.observe_node(o)
         return c
 
     return build, MC_NAMES

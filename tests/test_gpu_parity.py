@@ -13,7 +13,7 @@ import pytest
 from cedarsim_jl_amd import (PULSE, PWL, SIN, Circuit, CircuitSweep, ProductSweep, dc, dc_opts, frange, parse_spice,
                              parse_spice_file, tran, tran_opts)
 from cedarsim_jl_amd import bsim4_params as B4
-from cedarsim_jl_amd.workloads import (DFF_CHECK_Q, DFF_CHECK_TIMES, dff_array, dff_chain, gf180_resolver, inverter, rc_ladder)
+from cedarsim_jl_amd.workloads import (DFF_CHECK_Q, DFF_CHECK_TIMES, DFF_TSPAN, dff_array, dff_chain, gf180_resolver, inverter, rc_ladder)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -292,14 +292,40 @@ def test_dff_waveform_matches_oracle_rtol_1e4(E, O):
     rc, xo, _ = o.dc(dc_opts(abstol=1e-14))
     sv = np.linspace(0.0, 7e-7, 1401)
     tol = 1e-7
-    rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo[None, :])))
-    assert rc == 0
     rco, to, vo, xfo, sto = o.tran(0.0, 7e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo)))
-    assert rco == 0 and len(t) == len(to) == len(sv)
-    err = np.max(np.abs(v[:, :, 0] - vo))
+    assert rco == 0
+    # the oracle against BOTH step controllers, each asked for by name (the AUTO default must not decide what this test covers)
+    for stepper, want in (("device", 2), ("host", 1)):
+        rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo[None, :]), stepper=stepper))
+        assert rc == 0 and st["stepper"] == want, (stepper, rc, st["stepper"])
+        assert len(t) == len(to) == len(sv)
+        err = np.max(np.abs(v[:, :, 0] - vo))
+        assert err < 1e-4 * 5.0, (stepper, err)
+        for tt, q in zip(DFF_CHECK_TIMES, DFF_CHECK_Q):  # test/gf180_dff.jl:29-33
+            assert abs(np.interp(tt, t, v[0, :, 0]) - q) < 1e-4
+    rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo[None, :])))
+    assert rc == 0 and st["stepper"] == 2   # AUTO takes the device-resident controller for this circuit
+
+
+def test_lockstep_device_kernel_six_tiles_matches_oracle(E, O):
+    """The lock-step form of the device-resident controller (PM_LOCKSTEP: no saveat grid, ONE step sequence for all blocks, a
+    grid-wide reduction per attempt across two workgroups) against the oracle: six tiles, tight tolerances, every accepted step
+    saved; the oracle is sampled at the engine's own time points through its dense output."""
+    c = dff_array(6, observe="q")
+    e, o = E(c), O(c)
+    rc, xo, _ = o.dc(dc_opts(abstol=1e-14))
+    assert rc == 0
+    tol = 1e-7
+    rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(abstol=tol, reltol=tol, skip_dc=True, dc=dc_opts(x0=xo[None, :])))
+    assert rc == 0 and st["stepper"] == 2 and st["stepper_mode"] == 1, (rc, st["stepper"], st["stepper_mode"])
+    assert len(t) == st["naccept"] + 1 and v.shape == (6, len(t), 1)
+    keep = np.concatenate(([True], np.diff(t) > 0))          # a restart after a break point may repeat a time
+    sv = t[keep]
+    rco, to, vo, _, _ = o.tran(0.0, 7e-7, tran_opts(abstol=tol, reltol=tol, saveat=sv, skip_dc=True, dc=dc_opts(x0=xo)))
+    assert rco == 0 and len(to) == len(sv)
+    err = np.max(np.abs(v[:, keep, 0] - vo))
     assert err < 1e-4 * 5.0, err
-    for tt, q in zip(DFF_CHECK_TIMES, DFF_CHECK_Q):  # test/gf180_dff.jl:29-33
-        assert abs(np.interp(tt, t, v[0, :, 0]) - q) < 1e-4
+    assert np.max(np.abs(v[:, :, 0] - v[0:1, :, 0])) < 1e-9   # tile equivalence inside one step sequence
 
 
 def test_dff_reference_gate_from_cold_start():
@@ -357,6 +383,25 @@ def test_full_size_array_properties(E):
     assert np.max(np.abs(q - np.array(DFF_CHECK_Q)[None, :])) < 1e-4
     assert np.max(np.abs(q - q[0:1])) < 1e-9  # tile equivalence
     assert st["n_block_iters"] >= 1024 * st["naccept"]
+
+
+def test_bench_instantiation_is_the_lockstep_device_kernel_at_full_size(E):
+    """Exactly what bench.py times: the 1024-DFF array, NO saveat grid, abstol = reltol = 1e-4 — must run
+    `tran_persistent_kernel<12, true, PM_LOCKSTEP>`: 1024 blocks on 256 workgroups, every accepted step saved, ONE time vector.
+    Properties: controller identity (stepper 2, mode 1), one row per accepted step, the reference's gate on tile 0, and the same
+    accepted / rejected / iteration counts as the host stepper (both implement one policy)."""
+    e = E(dff_array(1024, observe="q0"))
+    opts = dict(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14))
+    rc, t, v, xf, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(**opts))
+    assert rc == 0 and st["stepper"] == 2 and st["stepper_mode"] == 1, (rc, st["stepper"], st["stepper_mode"], e.ctx.last_error())
+    assert len(t) == st["naccept"] + 1 and v.shape == (1, len(t), 1) and t[0] == 0.0 and t[-1] == DFF_TSPAN[1]
+    assert st["step_kernel_launches"] == 1
+    for tt, q in zip(DFF_CHECK_TIMES, DFF_CHECK_Q):      # benchmarks/gf180_dff_solver_bench.jl:89-93: within 10 abstol
+        assert abs(np.interp(tt, t, v[0, :, 0]) - q) <= 10 * 1e-4
+    rc_h, t_h, v_h, _, st_h = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(stepper="host", **opts))
+    assert rc_h == 0 and st_h["stepper"] == 1
+    assert (st_h["naccept"], st_h["nreject"], st_h["nnonliniter"]) == (st["naccept"], st["nreject"], st["nnonliniter"])
+    assert np.max(np.abs(t_h - t)) < 1e-18 and np.max(np.abs(v_h - v)) < 1e-6
 
 
 # ------------------------------------------------------------------------------------------------
