@@ -118,19 +118,50 @@ class Solution:
         return path
 
     def __call__(self, t, idxs=None):
-        """`sol(t, idxs=…)`: observables between saved points by shape-preserving cubic (PCHIP) interpolation of the accepted
-        steps — third order where the waveform is smooth, no overshoot at the corners the stepper landed on.  The engine's own
-        dense output (the BDF polynomial, evaluated on the device) is what `saveat=` returns; use that for exact parity."""
+        """`sol(t, idxs=…)` (test/gf180_dff.jl:29-33).  A run without a `saveat` grid carries, per accepted step, the number of
+        newest saved points its BDF dense-output polynomial runs through (`ch_result_dense_points`): `sol(t)` evaluates exactly
+        that polynomial — the value a `saveat` grid would have returned at t.  Results that are already on a `saveat` grid are
+        interpolated between grid points by a shape-preserving cubic (PCHIP)."""
         names = idxs if isinstance(idxs, (list, tuple)) else [idxs]
         tt = np.asarray(self.t, float)
+        pts = self.stats.get("dense_points") if isinstance(self.stats, dict) else None
+        tq = np.atleast_1d(np.asarray(t, float))
+
+        def dense(y):
+            y = np.asarray(y, float)
+            out = np.empty(len(tq))
+            for q, x in enumerate(tq):
+                if x <= tt[0]:
+                    out[q] = y[0]
+                    continue
+                if x >= tt[-1]:
+                    out[q] = y[-1]
+                    continue
+                i = int(np.searchsorted(tt, x, side="left"))          # tt[i-1] < x <= tt[i]: the step that ended at row i covers x
+                m = min(int(pts[i]), i + 1)
+                rows = list(range(i - m + 1, i + 1))
+                if m < 2 or len(set(tt[rows])) < m:
+                    out[q] = np.interp(x, tt[i - 1:i + 1], y[i - 1:i + 1]) if tt[i] > tt[i - 1] else y[i]
+                    continue
+                acc = 0.0
+                for a in rows:
+                    w = 1.0
+                    for b in rows:
+                        if b != a:
+                            w *= (x - tt[b]) / (tt[a] - tt[b])
+                    acc += w * y[a]
+                out[q] = acc
+            return out if np.ndim(t) else float(out[0])
+
         uniq = np.concatenate(([True], np.diff(tt) > 0)) if len(tt) > 1 else np.ones(len(tt), bool)   # restart steps repeat a time
 
-        def interp(y):
+        def pchip(y):
             y = np.asarray(y, float)
             if uniq.sum() < 3:
                 return np.interp(t, tt, y)
             from scipy.interpolate import PchipInterpolator
             return PchipInterpolator(tt[uniq], y[uniq], extrapolate=False)(np.clip(t, tt[0], tt[-1]))
+        interp = dense if (pts is not None and len(pts) == len(tt) and np.any(np.asarray(pts) >= 2)) else pchip
         out = [interp(self[n]) for n in names]
         out = [float(o) if np.ndim(o) == 0 else o for o in out]
         return out if isinstance(idxs, (list, tuple)) else out[0]

@@ -186,6 +186,7 @@ constexpr int NSLOT = 8;  // 7 history points + 1 candidate
 
 struct ch_result {
   std::vector<double> times, values, final_state;
+  std::vector<int32_t> pts;   // per saved row: newest saved points (this row included) the step's dense-output polynomial runs through; 0 = none
   ch_stats stats;
   int status = CH_OK;
   int n_obs = 0, S = 1;
@@ -1237,7 +1238,7 @@ struct ch_circuit {
     HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(wg_consts ? bps_all : bps, st));
     if (wg_consts) { HIPCHK(d_pwgc.upload(wgc, st)); HIPCHK(d_pwgk.upload(wgk, st)); }
     { std::vector<double> sv(o.saveat, o.saveat + std::max(0, o.n_saveat)); if (sv.empty()) sv.push_back(0.0); HIPCHK(d_psave.upload(sv, st)); }
-    HIPCHK(d_ptimes.alloc((size_t)max_rows)); HIPCHK(d_prows.alloc((size_t)max_rows * row_d));
+    HIPCHK(d_ptimes.alloc((size_t)2 * max_rows)); /* [times | dense-output point counts] */ HIPCHK(d_prows.alloc((size_t)max_rows * row_d));
     HIPCHK(d_wgrec.alloc((size_t)2 * n_wg * 16)); HIPCHK(d_grprec.alloc(2 * 8 * 16)); /* 16 granules per record, double-buffered by generation parity */ HIPCHK(d_pcnt.alloc(10 * 32)); HIPCHK(d_pctl.alloc(2));   /* controller state in; [1]: exit state of a batch with per-sample steps */
     PersistArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.a = base;
@@ -1269,7 +1270,9 @@ struct ch_circuit {
       pa.bd_kind[q] = bd.kind; pa.bd_ta[q] = bd.ta; pa.bd_tb[q] = bd.tb;
       pa.bd_val[q] = bd.kind == K_R ? h_dmult0[bd.hdev] / h_dpar0[bd.hdev] : h_dmult0[bd.hdev] * h_dpar0[bd.hdev];
     }
-    const bool coop = !pa.indep || nblk <= PW * n_cu;   // without grid-wide waits the workgroups may queue behind each other
+    // Own steps: no grid-wide wait anywhere in the kernel, so the workgroups need not be co-resident — an ordinary launch whose
+    // workgroups may queue (behind each other, or behind another process's kernel: a cooperative launch would be refused there)
+    const bool coop = !pa.indep;
     pa.pair_dbg = std::getenv("CEDARHIP_PAIR_DBG") ? std::atoi(std::getenv("CEDARHIP_PAIR_DBG")) : 0;
     // initial controller state (same first step as the host stepper)
     TranCtl cs; std::memset(&cs, 0, sizeof(cs));
@@ -1288,7 +1291,7 @@ struct ch_circuit {
       if (lds + fa.sharedSizeBytes > 160 * 1024) { set_err("device-resident stepper: LDS footprint"); return CH_OK; }
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((160 * 1024 - (int)fa.sharedSizeBytes) & ~255)));
     }
-    std::vector<double> hrows, htimes;
+    std::vector<double> hrows, htimes, hpts;
     bool single_batch = false;
     std::vector<std::vector<double>> row_store;   // drained batches when the row buffer fills (no saveat)
     int resume = 0, status = CH_OK;
@@ -1296,6 +1299,7 @@ struct ch_circuit {
       HIPCHK(hipMemcpyAsync(d_pctl.p, &cs, sizeof(cs), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(d_pctl.p + 1, &cs, sizeof(cs), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemsetAsync(d_pcnt.p, 0, 10 * 32 * sizeof(unsigned), st));
+      HIPCHK(hipMemsetAsync(d_ptimes.p + max_rows, 0, (size_t)max_rows * sizeof(double), st));
       HIPCHK(hipMemsetAsync(d_wgrec.p, 0, (size_t)2 * n_wg * 16 * sizeof(double), st)); HIPCHK(hipMemsetAsync(d_grprec.p, 0, 2 * 8 * 16 * sizeof(double), st));   // generation tags start at 0
       pa.resume = resume;
       void* kargs[] = {(void*)&pa};
@@ -1319,10 +1323,11 @@ struct ch_circuit {
       // [observable][time][sample] and cross PCIe once, straight into the result (the host-side transposition of a result with
       // every node observed, 100 MB for the 1024-DFF array, cost several times the solve).  Drained batches keep the host path.
       single_batch = resume == 0 && cs.exit_reason != PX_ROWS_FULL && !dcm;
-      htimes.resize(base_t + nr);
+      htimes.resize(base_t + nr); hpts.resize(base_t + nr);
       if (!single_batch) hrows.resize((base_t + nr) * row_d);
       if (nr > 0) {
         HIPCHK(hipMemcpy(htimes.data() + base_t, d_ptimes.p, nr * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hpts.data() + base_t, d_ptimes.p + max_rows, nr * sizeof(double), hipMemcpyDeviceToHost));
         if (!single_batch) HIPCHK(hipMemcpy(hrows.data() + base_t * row_d, d_prows.p, nr * row_d * sizeof(double), hipMemcpyDeviceToHost));
       }
       if (cs.exit_reason == PX_ROWS_FULL) { cs.nsaved = 0; resume = 1; continue; }
@@ -1355,6 +1360,8 @@ struct ch_circuit {
     R.stats.nfactors += arr_iters; R.stats.nsolve += arr_iters;
     const size_t nt = htimes.size();
     R.times = htimes;
+    R.pts.assign(nt, 0);
+    if (own_steps == false) for (size_t r = 0; r < nt; ++r) R.pts[r] = (int32_t)hpts[r];
     R.values.assign((size_t)n_obs * nt * S, 0.0);
     if (single_batch) {
       const size_t n = (size_t)n_obs * nt * S;
@@ -1459,7 +1466,7 @@ struct ch_circuit {
       }
     }
     auto tstart = hclock::now();
-    R.times.clear(); R.values.clear(); R.final_state.clear();   // (a launch that gave up may have left the rows of its first attempt)
+    R.times.clear(); R.pts.clear(); R.values.clear(); R.final_state.clear();   // (a launch that gave up may have left the rows of its first attempt)
     std::memset(&R.stats, 0, sizeof(R.stats));
     R.S = S; R.n_obs = (int)obs_kind.size();
     device_ms = 0; n_launch = 0; n_timed = 0;
@@ -1531,6 +1538,7 @@ struct ch_circuit {
           why = err();
         }
         if (want == CH_STEPPER_DEVICE || is_torn) { set_err("device-resident stepper not available for this circuit: " + why); return CH_ERR_UNSUPPORTED; }
+        if (std::getenv("CEDARHIP_DEBUG_STEPPER")) std::fprintf(stderr, "[stepper] host stepper because: %s\n", why.c_str());
       }
       if (is_torn) { set_err("the torn form of a circuit runs on the device-resident stepper only"); return CH_ERR_UNSUPPORTED; }
     }
@@ -1553,7 +1561,7 @@ struct ch_circuit {
         const int n = n_obs * S;
         hipLaunchKernelGGL(save_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, oa);
       }
-      R.times.push_back(ts); ++nsaved;
+      R.times.push_back(ts); R.pts.push_back(0); ++nsaved;
       return CH_OK;
     };
     auto free_chunks = [&]() { for (double* p : chunks) (void)hipFree(p); chunks.clear(); };
@@ -1628,8 +1636,8 @@ struct ch_circuit {
           rc = save(ts, order, ww + 1, m); if (rc) break;
           ++isave;
         }
-      } else if (n_obs > 0) { R.times.push_back(tn); ++nsaved; }  // the kernel's epilogue already wrote this row
-      else { const double one = 1.0; rc = save(tn, order, &one, 1); }
+      } else if (n_obs > 0) { R.times.push_back(tn); R.pts.push_back(std::min(kk, nh) + 1); ++nsaved; }  // the kernel's epilogue already wrote this row
+      else { const double one = 1.0; rc = save(tn, order, &one, 1); if (rc == CH_OK) R.pts.back() = std::min(kk, nh) + 1; }
       if (rc != CH_OK) { status = rc; break; }
       // ---- order / step selection ----
       const double fac_k = std::pow(2.0 * errk + 1e-4, -1.0 / (kk + 1));  // puts the error at half the tolerance
@@ -1940,6 +1948,7 @@ static int ch_tran_impl(ch_circuit* c, double t0, double t1, const ch_tran_opts*
 }
 int64_t ch_result_n_times(const ch_result* r) { return r ? (int64_t)r->times.size() : 0; }
 const double* ch_result_times(const ch_result* r) { return r ? r->times.data() : nullptr; }
+const int32_t* ch_result_dense_points(const ch_result* r) { return (r && r->pts.size() == r->times.size()) ? r->pts.data() : nullptr; }
 const double* ch_result_values(const ch_result* r) { return r ? r->values.data() : nullptr; }
 const double* ch_result_final_state(const ch_result* r) { return r ? r->final_state.data() : nullptr; }
 int ch_result_stats(const ch_result* r, ch_stats* s) { if (!r || !s) return CH_ERR_INVALID; *s = r->stats; return CH_OK; }

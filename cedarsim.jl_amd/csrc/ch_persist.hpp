@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
       }
     } else {
       if (my_ob >= 0) p.out_rows[(long long)nsaved * row_stride + (long long)my_ob * a.S + s] = Xh[head * nc + lane];
-      if (blk == 0 && lane == 0) p.out_times[nsaved] = tn;
+      if (blk == 0 && lane == 0) { p.out_times[nsaved] = tn; p.out_times[p.max_rows + nsaved] = (double)((kk < nh ? kk : nh) + 1); }   // + the points of the step's dense output
       ++nsaved;
     }
     // ---- order / step selection ----

@@ -19,7 +19,7 @@ _pi32 = C.POINTER(C.c_int32)
 EXPORTS = [
     "ch_dc_opts_default", "ch_tran_opts_default", "ch_create", "ch_destroy", "ch_last_error", "ch_circuit_build",
     "ch_circuit_free", "ch_circuit_info", "ch_circuit_maps", "ch_set_samples", "ch_set_params", "ch_dc", "ch_tran",
-    "ch_result_n_times", "ch_result_times", "ch_result_values", "ch_result_final_state", "ch_result_stats",
+    "ch_result_n_times", "ch_result_times", "ch_result_dense_points", "ch_result_values", "ch_result_final_state", "ch_result_stats",
     "ch_result_status", "ch_result_free", "ch_eval", "ch_ac", "ch_noise", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
     "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64", "ch_va_n_modules", "ch_va_find", "ch_va_module_name", "ch_va_module_info",
     "ch_va_node_name", "ch_va_param_name", "ch_va_eval", "ch_va_n_opvars", "ch_va_opvar_name", "ch_va_opvars",
@@ -57,6 +57,8 @@ def load_library():
     for f in ("ch_result_times", "ch_result_values", "ch_result_final_state"):
         getattr(L, f).restype = _pf64
         getattr(L, f).argtypes = [vp]
+    L.ch_result_dense_points.restype = _pi32
+    L.ch_result_dense_points.argtypes = [vp]
     L.ch_result_stats.argtypes = [vp, C.POINTER(ChStats)]
     L.ch_result_status.argtypes = [vp]
     L.ch_result_free.argtypes = [vp]
@@ -260,7 +262,11 @@ class EngineCircuit:
             xf = np.ctypeslib.as_array(fs, (S, self.n_mna)).copy() if fs and nt else np.zeros((S, self.n_mna))
             st = ChStats()
             self.L.ch_result_stats(r, C.byref(st))
-            return rc, t, v, xf, st.asdict()
+            sd = st.asdict()
+            dp = self.L.ch_result_dense_points(r)
+            # per saved row: how many newest rows the step's dense-output polynomial runs through (0: none; api.Solution.__call__)
+            sd["dense_points"] = np.ctypeslib.as_array(dp, (nt,)).copy() if (dp and nt) else None
+            return rc, t, v, xf, sd
         finally:
             self.L.ch_result_free(r)
 

@@ -262,6 +262,11 @@ int ch_tran(ch_circuit*, double t0, double t1, const ch_tran_opts*, ch_result** 
 int64_t ch_result_n_times(const ch_result*);
 const double* ch_result_times(const ch_result*);  /* [n_times]                                  */
 const double* ch_result_values(const ch_result*); /* [n_obs][n_times][n_samples]                */
+/* Dense output of a run WITHOUT a saveat grid (`sol(t, idxs=…)`, test/gf180_dff.jl:29-33): entry i is the number m of newest
+ * saved points, row i included, through which the polynomial of the step that ended at times[i] runs — for t in
+ * (times[i-1], times[i]] the solution is the Lagrange interpolant through rows i-m+1 .. i, which is what a saveat grid would
+ * have returned there.  0: no polynomial for this row (the initial state; every row of a run on a saveat grid).  [n_times] */
+const int32_t* ch_result_dense_points(const ch_result*);
 const double* ch_result_final_state(const ch_result*); /* [n_samples][n_mna] at the last time   */
 int ch_result_stats(const ch_result*, ch_stats*);
 int ch_result_status(const ch_result*);           /* CH_OK or CH_ERR_*                          */

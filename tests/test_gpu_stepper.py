@@ -345,3 +345,25 @@ def test_return_codes_of_both_step_controllers(E):
         assert rc == -4 and st["stepper_mode"] == mode, (stepper, extra.keys(), rc)                             # DtLessThanMin: the 1 ns edges need smaller steps
     rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14)))
     assert rc == 0          # and the circuit is fine afterwards
+
+
+def test_dense_output_after_the_fact_equals_the_saveat_grid(E):
+    """`sol(t, idxs=[sys.node_q])` (test/gf180_dff.jl:29-33) on a run WITHOUT a saveat grid: `ch_result_dense_points` tells, per
+    accepted step, through how many newest rows the step's BDF polynomial runs; evaluating it afterwards must give what the
+    engine's own dense output writes on a saveat grid for the same step sequence — on both step controllers."""
+    from cedarsim_jl_amd.api import Solution
+    c = dff_array(1, observe="q")
+    e = E(c)
+    sv = np.linspace(0.0, 7e-7, 351)[1:-1]
+    for stepper in ("device", "host"):
+        kw = dict(abstol=1e-5, reltol=1e-5, dc=dc_opts(abstol=1e-14), stepper=stepper)
+        rc, t, v, xf, st = e.tran(0.0, 7e-7, tran_opts(**kw))
+        assert rc == 0 and st["dense_points"] is not None and len(st["dense_points"]) == len(t)
+        assert st["dense_points"][0] == 0 and st["dense_points"][1:].min() >= 2 and st["dense_points"].max() <= 6
+        rc2, t2, v2, _, st2 = e.tran(0.0, 7e-7, tran_opts(saveat=sv, **kw))
+        assert rc2 == 0 and (st2["naccept"], st2["nreject"]) == (st["naccept"], st["nreject"])   # one block: the same step sequence
+        sol = Solution(c, t, {c.obs[0]: v[0, :, 0]}, None, rc, st)
+        got = sol(sv, idxs="q")
+        assert np.max(np.abs(got - v2[0, :, 0])) < 1e-9, (stepper, np.max(np.abs(got - v2[0, :, 0])))
+        lin = np.interp(sv, t, v[0, :, 0])
+        assert np.max(np.abs(lin - v2[0, :, 0])) > 10 * np.max(np.abs(got - v2[0, :, 0]))           # and it is not just linear interpolation
