@@ -228,6 +228,7 @@ struct ch_circuit {
   DevBuf<ClassMeta> d_classes;
   DevBuf<uint16_t> d_gl_src;
   DevBuf<double> d_rate;
+  DevBuf<unsigned char> d_perm;   // pivot order of every block's register LU (NewtonArgs::perm)
   DevBuf<double> d_dpar, d_dmult, d_mosp, d_kv, d_srcv, d_gmin, d_X, d_Q, d_dumpA, d_dumpF, d_dumpQ, d_dumpC, d_dumpG, d_dumpF0, d_temp, d_omega, d_xac, d_psd;
   DevBuf<int> d_noise_a, d_noise_b, d_noise_h, d_acfail;
   DevBuf<double> d_noise_pwr, d_noise_exp;
@@ -584,6 +585,7 @@ struct ch_circuit {
     HIPCHK(hipMemsetAsync(d_Q.p, 0, slot_elems * NSLOT * sizeof(double), st));
     HIPCHK(d_out.alloc((size_t)A.n_comp * S));
     { std::vector<double> ones((size_t)A.n_comp * S, 1.0); HIPCHK(d_rate.upload(ones, st)); }
+    HIPCHK(d_perm.alloc((size_t)A.n_comp * S * 16)); HIPCHK(hipMemsetAsync(d_perm.p, 0, (size_t)A.n_comp * S * 16, st));   // identity
     host_reduce = (size_t)A.n_comp * S <= 4096 && std::getenv("CEDARHIP_DEVICE_REDUCE") == nullptr;
     if (host_reduce && h_out_n < (size_t)A.n_comp * S) {
       if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; h_out_n = 0; }
@@ -608,7 +610,7 @@ struct ch_circuit {
     a.X = d_X.p; a.Qh = d_Q.p; a.slot_stride = (long)slot_elems; a.out = host_reduce ? h_out : d_out.p;
     a.unk_obs = d_unk_obs.p; a.n_obs = (int)obs_kind.size();
     a.bmeta = d_bmeta.p; a.dcls_local = d_dcls_local.p; a.comp_mc_ofs = d_mc_ofs.p; a.comp_mc_n = d_mc_n.p; a.mc_list = d_mc_list.p; a.max_mc = max_mc;
-    a.summary = h_sum; a.rate = d_rate.p;
+    a.summary = h_sum; a.rate = d_rate.p; a.perm = d_perm.p;
 #ifdef CH_STAMPS
     a.stamps = d_stamps.p;
 #endif
@@ -1134,6 +1136,8 @@ struct ch_circuit {
     if (n_cu == 0) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return no("hipGetDeviceProperties failed"); n_cu = prop.multiProcessorCount; }
     const long nblk = (long)A.n_comp * S;
     if (nblk > (long)PW * n_cu && !own_steps) return no("more blocks than resident wavefronts (4 per CU)");
+    // p_grid_reduce: 8 group leaders sweep at most 32 member workgroups each
+    if (!own_steps && (nblk + PW - 1) / PW > 256) return no("more than 256 workgroups in a grid-wide reduction");
     size_t npwl = 0; for (int i : needed_src) npwl += src[i].ts.size();
     if (!wg_consts && npwl > 2048) return no("piecewise-linear tables above 2048 points");
     return true;
@@ -1224,7 +1228,7 @@ struct ch_circuit {
       }
     }
     const size_t wave_d = persist_wave_doubles(wg_consts);
-    const size_t lds = (max_cd + (max_ci + 1) / 2 + PW * P_NREC + P_NREC + 4 + PW * wave_d) * sizeof(double);
+    const size_t lds = (max_cd + (max_ci + 1) / 2 + PW * P_NREC + P_NREC + 4 + P_SCR + PW * wave_d) * sizeof(double);
     // wave pairs share the device evaluation by function when every block has the same class and at most 32 evaluation slots
     const bool pair = A.classes.size() == 1 && h_cms[0].nslots <= 32 && std::getenv("CEDARHIP_PERSIST_NOPAIR") == nullptr;
     if (lds > 150 * 1024) { set_err("device-resident stepper: the workgroup's LDS footprint exceeds 150 KB"); return CH_OK; }
@@ -1300,6 +1304,8 @@ struct ch_circuit {
       HIPCHK(hipMemcpyAsync(d_pctl.p + 1, &cs, sizeof(cs), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemsetAsync(d_pcnt.p, 0, 10 * 32 * sizeof(unsigned), st));
       HIPCHK(hipMemsetAsync(d_ptimes.p + max_rows, 0, (size_t)max_rows * sizeof(double), st));
+      // own steps: a block that stops early (DtLessThanMin, MaxIters) never writes its later saveat rows; they read as NaN
+      if (pa.indep) HIPCHK(hipMemsetAsync(d_prows.p, 0xff, (size_t)max_rows * row_d * sizeof(double), st));
       HIPCHK(hipMemsetAsync(d_wgrec.p, 0, (size_t)2 * n_wg * 16 * sizeof(double), st)); HIPCHK(hipMemsetAsync(d_grprec.p, 0, 2 * 8 * 16 * sizeof(double), st));   // generation tags start at 0
       pa.resume = resume;
       void* kargs[] = {(void*)&pa};
@@ -2275,6 +2281,32 @@ static int ch_bench_triad_impl(ch_ctx* ctx, int64_t n, int32_t iters, double* gb
   *gbps_out = best;
   return best > 0 ? CH_OK : CH_ERR_DEVICE;
 }
+// Test hook: fills the LDS of every CU with a pattern that is a NaN as a double and a large negative number as an int, so that a
+// kernel which reads LDS it has not staged itself (LDS keeps whatever the previous kernel left there) gets garbage deterministically
+// instead of the zeros of a fresh process.  The round-2 abort of test_gpu_stepper.py (gpurun_out/r02_stepper6.log) was exactly
+// that: the helper wave of a pair read its OWN, unstaged slot table after a host-stepper kernel had used the CU.
+__global__ void poison_lds_kernel(unsigned* sink) {
+  extern __shared__ unsigned pl_[];
+  const int n = 160 * 1024 / 4 - 64;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) pl_[i] = 0xfff7a5a5u;
+  __syncthreads();
+  if (threadIdx.x == 0 && pl_[blockIdx.x % n] != 0xfff7a5a5u) *sink = 1u;   // keeps the stores alive
+}
+static int ch_debug_poison_lds_impl(ch_ctx* ctx) {
+  if (!ctx) return CH_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return CH_ERR_DEVICE;
+  unsigned* sink = nullptr;
+  if (hipMalloc((void**)&sink, sizeof(unsigned)) != hipSuccess) return CH_ERR_DEVICE;
+  const int lds = 160 * 1024 - 256;
+  (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  // one workgroup fills a CU's LDS; several rounds of n_cu workgroups so that every CU is reached whatever the dispatcher does
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(prop.multiProcessorCount * 8), dim3(256), lds, ctx->stream, sink);
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(sink);
+  if (e != hipSuccess) { ctx->err = std::string("poison_lds: ") + hipGetErrorString(e); return CH_ERR_DEVICE; }
+  return CH_OK;
+}
 static int ch_bench_fp64_impl(ch_ctx* ctx, int32_t iters, double* tflops_out) {
   if (!ctx || iters < 1 || !tflops_out) return CH_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
@@ -2384,12 +2416,13 @@ int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_i
 }
 int ch_bench_triad(ch_ctx* ctx, int64_t n, int32_t iters, double* gbps_out) { return guard_rc(ctx, [&] { return ch_bench_triad_impl(ctx, n, iters, gbps_out); }); }
 int ch_bench_fp64(ch_ctx* ctx, int32_t iters, double* tflops_out) { return guard_rc(ctx, [&] { return ch_bench_fp64_impl(ctx, iters, tflops_out); }); }
+int ch_debug_poison_lds(ch_ctx* ctx) { return guard_rc(ctx, [&] { return ch_debug_poison_lds_impl(ctx); }); }
 int ch_va_eval(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* st_out) {
   return guard_rc(ctx, [&] { return ch_va_eval_impl(ctx, id, par, v, temperature_k, gmin, st_out); });
 }
 int ch_va_opvars(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* op_out) {
   return guard_rc(ctx, [&] { return ch_va_opvars_impl(ctx, id, par, v, temperature_k, gmin, op_out); });
 }
-const char* ch_version(void) { return "cedarhip 0.2 (gfx950; fused block Newton, device-resident step controller)"; }
+const char* ch_version(void) { return "cedarhip 0.3 (gfx950; fused block Newton, device-resident step controller)"; }
 
 }  // extern "C"

@@ -93,6 +93,7 @@ struct NewtonArgs {
   BlockOut* out;
   Summary* summary;                          // output of reduce_blocks_kernel (mapped pinned host memory)
   double* rate;                              // [n_comp*S] last observed Newton convergence rate per block
+  unsigned char* perm;                       // [n_comp*S][16] pivot order of the block's register LU, stored as row ^ lane (0 = identity), or null
   int reset_rate;                            // 1: ignore the stored rates (after a restart / failure)
   double* obs_row;                           // [n_obs][S] candidate row of the observable buffer, or null
   double* dumpA; double* dumpF; double* dumpQ; double* dumpC; int dump_stride;  // MODE_EVAL: per-block dense dumps (A = G + alpha0*C, C)
@@ -376,7 +377,7 @@ template <int NCV> __device__ __forceinline__ int row_max_i(int v) {
 // the lane was 70 of the 130 instructions of a step.)  Returns false when the pivot column is zero
 // or not finite.  On return lane i holds x_i in `sol` (i < nc).
 template <int NC>
-__device__ __forceinline__ bool lu_solve_regs(double (&r)[NC + 1], int nc, int lane, double& sol) {
+__device__ __forceinline__ bool lu_solve_regs(double (&r)[NC + 1], int nc, int lane, double& sol, int* myrow_out = nullptr) {
   bool done = lane >= nc;
   int mystep = -1;       // elimination step at which this lane's row became the pivot row
   double ipiv = 0.0;     // reciprocal of this lane's pivot
@@ -412,7 +413,109 @@ __device__ __forceinline__ bool lu_solve_regs(double (&r)[NC + 1], int nc, int l
     }
   }
   sol = out;
+  if (myrow_out) {   // the row that was the pivot of step `lane`: loading the rows in this order puts every pivot on the diagonal
+    int mr = lane;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) if (k < nc && lane == k) mr = piv[k];
+    *myrow_out = mr;
+  }
   return true;
+}
+
+// ---- LU without a pivot search: rows pre-permuted into pivot order ----------------------------------------------------------
+// The pivot search is what the register LU above spends its instructions on (1 500 for NC = 12: 258 v_readlane with a
+// scalar-register lane select, 117 s_nop hazard pads, the retired-lane bookkeeping).  A circuit's Jacobian keeps its pivot order
+// from one Newton iteration to the next almost always (KLU's refactorisation reuses it for the same reason), so the rows are loaded
+// from LDS IN PIVOT ORDER — lane i takes row myrow(i), the row partial pivoting chose at step i the last time it ran — and the
+// elimination runs with the pivot of step k in lane k: a compile-time lane, so every broadcast is ONE v_mov_b64_dpp row_newbcast:k
+// (a DPP broadcast inside the 16-lane row; 64-bit DPP exists for exactly this control) and nothing is searched or retired.
+// What partial pivoting guarantees, |multiplier| <= 1, is CHECKED instead of enforced: every lane keeps the largest multiplier
+// magnitude it formed (one integer max per step on the high word), and ONE ballot at the end compares it with 8: beyond that, or
+// with a vanishing / non-finite pivot, the solve is repeated by lu_solve_regs (natural row order, full search), which also hands
+// back the new pivot order.  Threshold pivoting with |l| <= 8 loses at most three bits against |l| <= 1 — irrelevant for a Newton
+// correction, and the same bound sparse direct solvers run with (KLU's default is 1000).
+// Layout: r[0 .. NC-1] = matrix columns (zero beyond nc), r[NC] = right-hand side; rows beyond nc are zero.  NC <= 16.
+template <int K> __device__ __forceinline__ double row_bcast(double v) {
+  static_assert(K >= 0 && K < 16, "row_newbcast lane");
+  // (keep the builtin's result in a typed temporary: used directly as an argument of an overloaded function, clang 19 took it for a
+  //  64-bit INTEGER and converted it numerically)
+  const double b = __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, true);   // v_mov_b64_dpp row_newbcast:K (bound_ctrl: every lane is written, the old value is dead)
+  return b;
+}
+// q += sum_j c[j] * x_j with x_j = the value lane j holds (j < nc <= NC <= 16): one DPP row broadcast per term
+template <int NC, int J> struct RowDot {
+  static __device__ __forceinline__ double run(const double (&c)[NC], double x, int nc, double q) {
+    if constexpr (J < NC) {
+      if (J < nc) { const double xj = row_bcast<J>(x); q = fma(c[J], xj, q); }
+      return RowDot<NC, J + 1>::run(c, x, nc, q);
+    } else return q;
+  }
+};
+
+template <int NC, int K>
+struct LuStaticStep {
+  static __device__ __forceinline__ void fwd(double (&r)[NC + 1], int nc, int lane, int& lkey, double& ipiv) {
+    if constexpr (K < NC) {
+      if (K < nc) {
+        const double ipk = frcp(row_bcast<K>(r[K]));      // every lane of the row forms the same reciprocal
+        double pj[NC + 1];                                 // the pivot row, broadcast under the full exec mask
+#pragma unroll
+        for (int j = K + 1; j <= NC; ++j) pj[j] = row_bcast<K>(r[j]);
+        if (lane == K) ipiv = ipk;
+        if (lane > K) {                                    // one exec-masked region: the multiplier and the row update
+          const double l = r[K] * ipk;
+          lkey = max(lkey, __double2hiint(l) & 0x7fffffff);
+#pragma unroll
+          for (int j = K + 1; j <= NC; ++j) r[j] = fma(-l, pj[j], r[j]);
+        }
+      }
+      LuStaticStep<NC, K + 1>::fwd(r, nc, lane, lkey, ipiv);
+    }
+  }
+  // back substitution, Q from NC-1 down to 0 (instantiated as K = NC-1-Q)
+  static __device__ __forceinline__ void bwd(const double (&r)[NC + 1], int nc, int lane, double& rhs, double ipiv) {
+    if constexpr (K < NC) {
+      constexpr int Q = NC - 1 - K;
+      if (Q < nc && Q > 0) {
+        const double xk = row_bcast<Q>(rhs * ipiv);        // lane Q holds x_Q = rhs_Q / pivot_Q
+        if (lane < Q) rhs = fma(-r[Q], xk, rhs);
+      }
+      LuStaticStep<NC, K + 1>::bwd(r, nc, lane, rhs, ipiv);
+    }
+  }
+};
+template <int NC>
+__device__ __forceinline__ bool lu_solve_static(double (&r)[NC + 1], int nc, int lane_in, double& sol) {
+  static_assert(NC <= 16, "row_newbcast spans one 16-lane row");
+  // The lane id is made opaque: otherwise every predicate below (lane == K, lane > K, lane < Q for every K) is hoisted out of the
+  // caller's loops as a 64-bit mask in scalar registers — three dozen pairs that spill, each use then costing v_readlane pairs
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  int lkey = 0; double ipiv = 0.0;
+  LuStaticStep<NC, 0>::fwd(r, nc, lane, lkey, ipiv);
+  // |l| <= 8 everywhere: 0x40200000 is the high word of 8.0; a NaN or an infinity (vanished or non-finite pivot) compares above it.
+  // (The LAST pivot has no multipliers: a vanishing one shows as a non-finite solution, which every caller tests for.)
+  if (__ballot(lane < nc && lkey > 0x40200000)) return false;
+  double rhs = r[NC];
+  LuStaticStep<NC, 0>::bwd(r, nc, lane, rhs, ipiv);
+  sol = rhs * ipiv;
+  return true;
+}
+// The solve of one block from its LDS image A[nc][lda] (column nc = right-hand side): static pivot order first, full search on
+// failure.  `myrow` (per lane, kept by the caller across solves) is the pivot order; it starts as the identity.
+template <int NC>
+__device__ __forceinline__ bool lu_solve_block(const double* A, int lda, int nc, int lane, int& myrow, double& sol) {
+  const bool mine = lane < nc;
+  double r[NC + 1];
+  if constexpr (NC <= 16) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) r[j] = (mine && j < nc) ? A[myrow * lda + j] : 0.0;
+    r[NC] = mine ? A[myrow * lda + nc] : 0.0;
+    if (lu_solve_static<NC>(r, nc, lane, sol)) return true;
+  }
+#pragma unroll
+  for (int j = 0; j <= NC; ++j) r[j] = (mine && j <= nc) ? A[lane * lda + j] : 0.0;
+  return lu_solve_regs<NC>(r, nc, lane, sol, &myrow);
 }
 
 // Bordered block-diagonal form (ch_analysis.hpp, tearing): the block's last nb rows / columns are its replicas of the border
@@ -700,6 +803,11 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
     const int maxit = a.mode == MODE_EVAL ? 1 : a.maxit;
     const double rate_prev = (a.mode == MODE_TRAN && !a.reset_rate) ? a.rate[blk] : 1.0;
     double rate_new = -1.0, dn_prev = 0.0;  // wave 0 only
+    // pivot order of this block's register LU (lu_solve_block), kept from launch to launch
+    constexpr bool keep_order = NC > 0 && NC <= 16;
+    int myrow = lane;
+    if (keep_order && a.perm && wave == 0 && lane < nc && nc <= NC) myrow = lane ^ (int)a.perm[(long)blk * 16 + lane];
+    const int myrow_in = myrow;
     const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar + (long)s * a.va_stride,
                        WIDE ? a.temp_s[a.Stemp > 1 ? s : 0] + 273.15 : 300.15, a.vacache + (long)s * a.vac_stride, a.dvac};
     for (int it = 0; it <= maxit; ++it) {
@@ -794,9 +902,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
         } else if (regs) {
           constexpr int NCR = NC > 0 ? NC : 1;
           const bool mine = lane < nc;
-          double r[NCR + 1], cr[NCR];
-#pragma unroll
-          for (int j = 0; j <= NCR; ++j) r[j] = (mine && j <= nc) ? A[lane * lda + j] : 0.0;
+          double cr[NCR];
 #pragma unroll
           for (int j = 0; j < NCR; ++j) cr[j] = (mine && j < nc) ? Cm[lane * nc + j] : 0.0;
           const double Fi = mine ? Fv[lane] : 0.0, Qi = mine ? Qv[lane] : 0.0, xi = mine ? xl[lane] : 0.0, wi = mine ? wv[lane] : 0.0;
@@ -809,7 +915,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
           else if (it == maxit) { stop = 1; }
           else {
             double dx = 0.0;
-            const bool ok = lu_solve_regs<NCR>(r, nc, lane, dx);
+            const bool ok = lu_solve_block<NCR>(A, lda, nc, lane, myrow, dx);
             CH_STAMP(7);
             if (!ok) { status = 2; stop = 1; }
             else {
@@ -824,8 +930,11 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
               const double e2 = bcast(row_sum<NCR>(mine ? t * t : 0.0), 0);
               if (a.mode == MODE_TRAN) {
                 double q = Qi;
+                if constexpr (NCR <= 16) q = RowDot<NCR, 0>::run(cr, dx, nc, q);
+                else {
 #pragma unroll
-                for (int j = 0; j < NCR; ++j) if (j < nc) q = fma(cr[j], bcast(dx, j), q);
+                  for (int j = 0; j < NCR; ++j) if (j < nc) q = fma(cr[j], bcast(dx, j), q);
+                }
                 if (mine) qn[lane] = q;
               }
               if (lane == 0) s_ctl[2] += 1;
@@ -920,6 +1029,7 @@ __global__ __launch_bounds__(256, 1) void newton_block_kernel(const NewtonArgs a
         a.out[blk] = bo;
         if (a.mode == MODE_TRAN && s_ctl[1] == 0) a.rate[blk] = s_ctl[2] >= 2 ? fmin(1.0, fmax(rate_new, 1e-4)) : fmin(1.0, rate_prev * 1.5);
       }
+      if (keep_order && a.perm && lane < nc && nc <= NC && myrow != myrow_in) a.perm[(long)blk * 16 + lane] = (unsigned char)(myrow ^ lane);
     }
   }
   CH_STAMP(4);

@@ -37,6 +37,7 @@ namespace chip {
 constexpr int PW = 4;          // blocks (= wavefronts) per workgroup
 constexpr int P_MAXSRC = 64;   // sources evaluated per attempt: one lane each
 constexpr int P_NREC = 8;      // doubles per reduction record
+constexpr int P_SCR = 64;      // doubles of cross-row scratch of the grid reduction (wave 0 of the workgroup)
 enum { PX_RUNNING = 0, PX_DONE = 1, PX_ROWS_FULL = 2, PX_ABORT = 3 };
 
 // controller state + statistics: written by workgroup 0 at exit, read back at start when `resume` is set
@@ -221,14 +222,26 @@ typedef unsigned long long p_u64;
 __device__ __forceinline__ p_u64 ld_gran(const p_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_gran(p_u64* p, p_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // lanes 2f and 2f+1 of every 16-lane group hold the low and the high half of field f: both get the double back
+// (the partner's half comes through a DPP quad permutation — one VALU instruction, no LDS crossbar trip)
 __device__ __forceinline__ double p_join(p_u64 gran, int lane) {
-  const unsigned mine = (unsigned)gran, other = (unsigned)__shfl_xor((int)mine, 1);
+  const unsigned mine = (unsigned)gran, other = (unsigned)dpp_i<DPP_QP_1032>((int)mine);
   const unsigned lo = (lane & 1) ? other : mine, hi = (lane & 1) ? mine : other;
   return __hiloint2double((int)hi, (int)lo);
 }
 __device__ __forceinline__ p_u64 p_split(double v, int lane, unsigned gen) {
   const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
   return ((p_u64)gen << 32) | half;
+}
+// combine the four 16-lane rows of a wave lane by lane, in a fixed order: (row0 op row1) op (row2 op row3).  Through LDS (one store,
+// four loads in flight) — the cross-row shuffles of the compiler (ds_bpermute pairs per double and step) were a fifth of the
+// reduction's instruction stream.  scr: 64 doubles of the calling wave's own scratch.
+__device__ __forceinline__ double p_rows4(double v, bool is_max, double* scr, int lane) {
+  scr[lane] = v;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int c = lane & 15;
+  const double a0 = scr[c], a1 = scr[16 + c], a2 = scr[32 + c], a3 = scr[48 + c];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return is_max ? fmax(fmax(a0, a1), fmax(a2, a3)) : (a0 + a1) + (a2 + a3);
 }
 template <bool ALL_SUM = false>   // ALL_SUM: every field combined with + (the Schur-complement and norm records of the bordered form)
 __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const double* rec /* 8 wave-uniform values */, double* part, double* summ,
@@ -247,6 +260,7 @@ __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const d
   unsigned* abort_flag = p.counters + 9 * 32;
   p_u64* wrec = (p_u64*)p.wg_rec + (size_t)(gen & 1) * p.n_wg * 16;
   p_u64* grec = (p_u64*)p.grp_rec + (size_t)(gen & 1) * 8 * 16;
+  double* scr = part + PW * P_NREC + P_NREC + 4;   // P_SCR doubles behind [part | summ | pair flags]: see the LDS layout of the kernel
   if (wave == 0) {
     bool ok = true;
     double v = part[f];
@@ -260,6 +274,7 @@ __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const d
         p_u64 x[8];
         for (;;) {
           bool all = true;
+          const unsigned ab = ld_agent_u(abort_flag);   // travels with the sweep: one round trip per poll, not two
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const int mm = q * 4 + m4;
@@ -267,24 +282,25 @@ __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const d
             all = all && (unsigned)(x[q] >> 32) == gen;
           }
           if (__all(all)) break;
-          if (ld_agent_u(abort_flag) != 0u) { ok = false; break; }
+          if (ab != 0u) { ok = false; break; }
           if (wall_clock64() - t0 > p.spin_ticks) { __hip_atomic_store(abort_flag, 1u | (gen << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }   // diagnostic: site 1, generation
           __builtin_amdgcn_s_sleep(1);
         }
-        double acc = 0.0;
+        // members q*4 + m4 of this lane's row, q ascending, then the four rows: a fixed order
+        double acc = (m4 < members) ? p_join(x[0], lane) : 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          double u = (q * 4 + m4 < members) ? p_join(x[q], lane) : 0.0;
-          u = fmaxop ? fmax(u, __shfl_xor(u, 16)) : u + __shfl_xor(u, 16);
-          u = fmaxop ? fmax(u, __shfl_xor(u, 32)) : u + __shfl_xor(u, 32);
+        for (int q = 1; q < 8; ++q) {
+          const double u = (q * 4 + m4 < members) ? p_join(x[q], lane) : 0.0;
           acc = fmaxop ? fmax(acc, u) : acc + u;
         }
+        acc = p_rows4(acc, fmaxop, scr, lane);
         if (lane < 16) st_gran(grec + (size_t)grp * 16 + g16, p_split(acc, lane, gen));
       }
       // every workgroup: the group records (8 x 16 granules = two per lane)
       p_u64 y[2];
       for (;;) {
         bool all = true;
+        const unsigned ab = ok ? ld_agent_u(abort_flag) : 1u;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int gg = q * 4 + m4;
@@ -292,19 +308,13 @@ __device__ inline bool p_grid_reduce(const PersistArgs& p, unsigned gen, const d
           all = all && (unsigned)(y[q] >> 32) == gen;
         }
         if (__all(all) || !ok) break;
-        if (ld_agent_u(abort_flag) != 0u) { ok = false; break; }
+        if (ab != 0u) { ok = false; break; }
         if (wall_clock64() - t0 > p.spin_ticks) { __hip_atomic_store(abort_flag, 2u | (gen << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }   // site 2
         __builtin_amdgcn_s_sleep(1);
       }
-      double acc = 0.0;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        double u = (q * 4 + m4 < n_grp) ? p_join(y[q], lane) : 0.0;
-        u = fmaxop ? fmax(u, __shfl_xor(u, 16)) : u + __shfl_xor(u, 16);
-        u = fmaxop ? fmax(u, __shfl_xor(u, 32)) : u + __shfl_xor(u, 32);
-        acc = fmaxop ? fmax(acc, u) : acc + u;
-      }
-      v = acc;
+      double acc = (m4 < n_grp) ? p_join(y[0], lane) : 0.0;
+      { const double u = (4 + m4 < n_grp) ? p_join(y[1], lane) : 0.0; acc = fmaxop ? fmax(acc, u) : acc + u; }
+      v = p_rows4(acc, fmaxop, scr, lane);
     }
     if (lane < 16 && !(lane & 1)) summ[f] = v;
     if (lane == 0) *s_abort = ok ? 0 : 1;
@@ -352,7 +362,7 @@ __device__ __forceinline__ double p_coef(double tau0, const double* tsl, int hea
   return q;
 }
 
-// LDS per workgroup: [consts: cd doubles | ci ints] [part PW*8 | summ 8] [PW wave regions]
+// LDS per workgroup: [consts: cd doubles | ci ints] [part PW*8 | summ 8 | pair flags 4 | reduction scratch P_SCR] [PW wave regions]
 // wave region (doubles): st[ndev*41] | A[nc*(nc+1)] | Cm[nc*nc] | xl xp F Q hq w qn pm pp x0 dm [11*nc] | Xh[8*nc] | Qh[8*nc] | tsl[8] | coef[48]
 //                        | kvl[nk] svl[nsrc] | pl[max_mc*B4L_STRIDE] | ints: class blob, MOS class list
 // PAIR: the two waves of a pair (2q, 2q+1) share the device evaluation of their two blocks BY FUNCTION (eval_cached): wave
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   double* part = cdl + p.n_cd + ((p.n_ci + 1) >> 1);
   double* summ = part + PW * P_NREC;
   int* pfl = (int*)(summ + P_NREC);   // per pair: {sequence of wave 2q, of wave 2q+1, done flag of block 2q, of block 2q+1}
-  double* W = summ + P_NREC + 4 + (size_t)wave * p.wave_doubles;
+  double* W = summ + P_NREC + 4 + P_SCR + (size_t)wave * p.wave_doubles;
   constexpr bool own = MODE == PM_OWN;
   const int* const wgc = own ? p.wgc : nullptr;
   const double* bps_own = nullptr; int nbp_own = 0;   // per-workgroup break points (the other modes read p.bps / p.nbp where they need them)
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   const bool live_h = PAIR && blk_h < p.nblk;
   const int bqh = live_h ? blk_h : 0, c_h = bqh / a.S, s_h = bqh - c_h * a.S;
   const int uofs_h = PAIR ? a.bmeta[c_h].uofs : uofs, dofs_h = PAIR ? a.bmeta[c_h].dofs : dofs;
-  double* Wh = summ + P_NREC + 4 + (size_t)((wave & ~1) + half) * p.wave_doubles;   // region of this lane's block (same class, same layout)
+  double* Wh = summ + P_NREC + 4 + P_SCR + (size_t)((wave & ~1) + half) * p.wave_doubles;   // region of this lane's block (same class, same layout)
   double* st_h = Wh; double* xl_h = Wh + (xl - W); double* pl_h = Wh + (pl - W);
   // the slot table too comes from the region of the lane's block: a wave without a block of its own (odd block count, single
   // circuit) has staged nothing into its own region and only helps its partner
@@ -496,6 +506,10 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     if (lane == 0) { stl[ST_ACC] = cs->naccept; stl[ST_REJ] = cs->nreject; stl[ST_FAIL] = cs->nconvfail; stl[ST_ITERS] = cs->sum_iters; stl[ST_BITERS] = cs->sum_block_iters; stl[ST_ATT] = cs->n_attempts; }
   }
   double rate_prev = 1.0;
+  // pivot order of the block's register LU (lu_solve_block): lane i loads row myrow; kept for the whole transient, and across
+  // launches / step controllers through a.perm (row ^ lane per unknown, 0 = identity)
+  int myrow = lane;
+  if (MODE != PM_BORDER && a.perm && mine) myrow = lane ^ (int)a.perm[(long)blk * 16 + lane];
   lds_fence();
   __syncthreads();
 
@@ -687,8 +701,10 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         P_STAMP(5);   // gather
         constexpr int NCR = NC;
         double r[NCR + 1], cr[NCR];
+        if constexpr (MODE == PM_BORDER) {   // (the other forms load their rows in pivot order inside lu_solve_block)
 #pragma unroll
-        for (int j = 0; j <= NCR; ++j) r[j] = (mine && j <= nc) ? A[lane * lda + j] : 0.0;
+          for (int j = 0; j <= NCR; ++j) r[j] = (mine && j <= nc) ? A[lane * lda + j] : 0.0;
+        }
 #pragma unroll
         for (int j = 0; j < NCR; ++j) cr[j] = (mine && j < nc) ? Cm[lane * nc + j] : 0.0;
         const double Fi = mine ? Fv[lane] : 0.0, Qi = mine ? Qv[lane] : 0.0, xi = mine ? xl[lane] : 0.0, wi = mine ? wv[lane] : 0.0;
@@ -852,7 +868,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         else {
           double dx = 0.0;
           P_STAMP(6);   // row loads, residual norm
-          const bool ok = lu_solve_regs<NCR>(r, nc, lane, dx);
+          const bool ok = lu_solve_block<NCR>(A, lda, nc, lane, myrow, dx);
           P_STAMP(7);   // LU + triangular solves
           if (!ok) { nstat = 2; stop = true; }
           else {
@@ -861,9 +877,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
             const bool bad = mine && (!(xn == xn) || fabs(xn) > 1e300);
             const double tq = dx * wi;
             const double e2 = bcast(row_sum<NCR>(mine ? tq * tq : 0.0), 0);
-            double q = Qi;
-#pragma unroll
-            for (int j = 0; j < NCR; ++j) if (j < nc) q = fma(cr[j], bcast(dx, j), q);
+            const double q = RowDot<NCR, 0>::run(cr, dx, nc, Qi);
             if (mine) qn[lane] = q;
             ++iters;
             if (__ballot(bad)) { nstat = 2; stop = true; }
@@ -1036,6 +1050,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     if (status == CH_OK && t < p.t1) status = CH_ERR_MAXSTEPS;
   }
   // ---- write the ring back in canonical order (slot j = j-th newest) and the controller state ----
+  if (MODE != PM_BORDER && a.perm && mine) a.perm[(long)blk * 16 + lane] = (unsigned char)(myrow ^ lane);
   if (mine) {
 #pragma unroll
     for (int j = 0; j < 7; ++j) {

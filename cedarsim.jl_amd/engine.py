@@ -22,7 +22,7 @@ EXPORTS = [
     "ch_result_n_times", "ch_result_times", "ch_result_dense_points", "ch_result_values", "ch_result_final_state", "ch_result_stats",
     "ch_result_status", "ch_result_free", "ch_eval", "ch_ac", "ch_noise", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
     "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64", "ch_va_n_modules", "ch_va_find", "ch_va_module_name", "ch_va_module_info",
-    "ch_va_node_name", "ch_va_param_name", "ch_va_eval", "ch_va_n_opvars", "ch_va_opvar_name", "ch_va_opvars",
+    "ch_va_node_name", "ch_va_param_name", "ch_va_eval", "ch_va_n_opvars", "ch_va_opvar_name", "ch_va_opvars", "ch_debug_poison_lds",
 ]
 
 _lib = None
@@ -141,6 +141,13 @@ class Context:
         if rc != 0:
             raise RuntimeError("ch_va_opvars failed: %s" % self.last_error())
         return {self.L.ch_va_opvar_name(int(module_id), k).decode(): float(out[k]) for k in range(n)}
+
+    def poison_lds(self):
+        """Test hook: leave every CU's LDS full of garbage (ch_debug_poison_lds)."""
+        self.L.ch_debug_poison_lds.argtypes = [C.c_void_p]
+        rc = self.L.ch_debug_poison_lds(self.h)
+        if rc != 0:
+            raise RuntimeError("ch_debug_poison_lds failed: %s" % self.last_error())
 
     def triad_gbps(self, n_doubles=1 << 27, iters=5):
         """Measured STREAM-triad bandwidth of this GPU in GB/s (measurement utility)."""

@@ -1009,8 +1009,14 @@ def generate_header(modules, source_tag=""):
         for k, node in enumerate(mo.nodes):
             dk = g.ddx_nodes.index(node) if node in g.ddx_nodes else -1
             out.append("      V[%d] = va::seed1(v[%d], dir == %d, %d, (R*)nullptr);" % (k, k, k, dk))
-        out.append("      if (part != 1) m_%s::eval<R, 0>(P, C, V, env, I, Q);" % mo.name)
-        out.append("      if (part != 0) m_%s::eval<R, 1>(P, C, V, env, I, Q);" % mo.name)
+        if len(mo.params) >= 64:
+            # a large model: the engine splits it into a resistive and a charge half (ch_engine.hip, slot bits 29/30); the whole record
+            # (CEDARHIP_VA_NOSPLIT, a diagnostic) is the two halves in sequence — no third instantiation of a 57 k-instruction function
+            out.append("      if (part != 1) m_%s::eval<R, 0>(P, C, V, env, I, Q);" % mo.name)
+            out.append("      if (part != 0) m_%s::eval<R, 1>(P, C, V, env, I, Q);" % mo.name)
+        else:
+            # a small model is never split: ONE evaluation (two half instantiations would run the shared front end twice)
+            out.append("      m_%s::eval<R, -1>(P, C, V, env, I, Q);" % mo.name)
         out.append("      for (int k = 0; k < %d; ++k) {" % nt)
         out.append("        if (part != 1) { if (first) st[k] = m * va::val(I[k]); st[16 + k * 8 + dir] = m * va::val(I[k].d[0]); }")
         out.append("        if (part != 0) { if (first) st[8 + k] = m * va::val(Q[k]); st[80 + k * 8 + dir] = m * va::val(Q[k].d[0]); }")

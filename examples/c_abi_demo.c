@@ -2,13 +2,47 @@
  * Circuit: V1 (PWL step 0 -> 1 V in 1 ns) - R1 (1 kOhm) - C1 (1 nF) to ground.  DC operating point, then a transient to
  * 5 tau with the node voltage saved at five times; compared with the closed form 1 - exp(-t/RC).
  * Build:  gcc -O2 -Iinclude examples/c_abi_demo.c -Lcedarsim.jl_amd/lib -lcedarhip -Wl,-rpath,$PWD/cedarsim.jl_amd/lib -lm -o c_abi_demo */
+#define _GNU_SOURCE
 #include <math.h>
+#include <fcntl.h>
+#include <signal.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <ucontext.h>
+#include <unistd.h>
 
 #include "cedarhip.h"
 
+/* CEDARHIP_DEMO_MAPS=1: attribute a crash at process exit (seen under rocprofv3: SIGSEGV inside __cxa_finalize after main has
+ * returned 0).  A SIGSEGV handler prints the faulting address and instruction pointer, then /proc/self/maps, so that the frame
+ * can be assigned to a mapped object (libcedarhip.so's fat-binary unregistration, the HIP runtime, or the profiler's tool
+ * library); the same dump is also written once at the normal end of main.  Async-signal-safe calls only. */
+static void dump_maps(void) {
+  char buf[4096];
+  FILE* f = fopen("/proc/self/maps", "r");
+  if (!f) return;
+  while (fgets(buf, sizeof buf, f)) if (strstr(buf, " r-xp ") || strstr(buf, "cedarhip") || strstr(buf, "rocprof") || strstr(buf, "amdhip")) fputs(buf, stderr);
+  fclose(f);
+}
+static void on_segv(int sig, siginfo_t* si, void* uc_) {
+  ucontext_t* uc = (ucontext_t*)uc_;
+  char line[160];
+  int n = snprintf(line, sizeof line, "[c_abi_demo] signal %d: fault address %p, instruction pointer %p\n", sig, si->si_addr,
+                   (void*)uc->uc_mcontext.gregs[REG_RIP]);
+  if (n > 0) (void)!write(2, line, (size_t)n);
+  int fd = open("/proc/self/maps", 0);
+  if (fd >= 0) { char b[4096]; ssize_t k; while ((k = read(fd, b, sizeof b)) > 0) (void)!write(2, b, (size_t)k); close(fd); }
+  _exit(128 + sig);
+}
+
 int main(void) {
+  if (getenv("CEDARHIP_DEMO_MAPS")) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = on_segv; sa.sa_flags = SA_SIGINFO;
+    sigaction(SIGSEGV, &sa, NULL);
+  }
   char err[512];
   ch_ctx* ctx = ch_create(0, err, sizeof err);
   if (!ctx) { fprintf(stderr, "ch_create: %s\n", err); return 2; }   /* no CPU fallback */
@@ -65,5 +99,6 @@ int main(void) {
   ch_result_free(r);
   ch_circuit_free(c);
   ch_destroy(ctx);
+  if (getenv("CEDARHIP_DEMO_MAPS")) { fprintf(stderr, "[c_abi_demo] main ends normally; executable mappings:\n"); dump_maps(); }
   return worst < 1e-5 && nt == 5 ? 0 : 1;
 }

@@ -343,6 +343,10 @@ int ch_bench_triad(ch_ctx*, int64_t n_doubles, int32_t iters, double* gbps_out);
  * best of `iters` passes in TFLOP/s (the eval kernel's fp64 rate is reported against this). */
 int ch_bench_fp64(ch_ctx*, int32_t iters, double* tflops_out);
 
+/* ---- test hook: fill the LDS of every CU with a NaN / negative-integer pattern (LDS keeps what the previous kernel left; a
+ * kernel that reads LDS it did not stage must not get away with a fresh process's zeros).  No reference counterpart. ---- */
+int ch_debug_poison_lds(ch_ctx*);
+
 #ifdef __cplusplus
 }
 #endif

@@ -367,3 +367,27 @@ def test_dense_output_after_the_fact_equals_the_saveat_grid(E):
         assert np.max(np.abs(got - v2[0, :, 0])) < 1e-9, (stepper, np.max(np.abs(got - v2[0, :, 0])))
         lin = np.interp(sv, t, v[0, :, 0])
         assert np.max(np.abs(lin - v2[0, :, 0])) > 10 * np.max(np.abs(got - v2[0, :, 0]))           # and it is not just linear interpolation
+
+
+def test_waves_without_a_block_never_read_unstaged_lds(E):
+    """The abort of round 2 (gpurun_out/r02_stepper6.log: SIGABRT inside ch_tran on the DEVICE run that followed a HOST run of the same
+    circuit; the same test alone, in a fresh process, passed): the helper wave of a wave pair that owns no block read the slot table
+    of its OWN LDS region, which nothing had staged — zeros in a fresh process, but whatever the previous kernel left on that CU
+    otherwise — and formed device-table addresses from it: an out-of-bounds global read, which the runtime answers with abort().
+    Fixed in 9f26d32 ("helper waves read their partner's tables").  This test makes the condition deterministic: every CU's LDS is
+    filled with a NaN / negative-integer pattern before each device-stepper run of circuits that leave waves without a block — a
+    single DFF (one live wave + its helper), 5 tiles on own steps, and torn arrays of 9 and 10 tiles — and the results must equal the
+    runs on clean LDS."""
+    cases = [(dff_array(1, observe="q"), {}), (dff_array(5, observe="q"), {"saveat": np.linspace(0.0, 3e-7, 31)}),
+             (dff_array(9, observe="q", supply_r=1.0), {"saveat": np.linspace(0.0, 3e-7, 31)}),
+             (dff_array(10, observe="q", supply_r=1.0), {"saveat": np.linspace(0.0, 3e-7, 31)})]
+    for ckt, extra in cases:
+        e = E(ckt)
+        kw = dict(abstol=1e-5, reltol=1e-5, dc=dc_opts(abstol=1e-12), stepper="device", **extra)
+        rc0, t0, v0, _, st0 = e.tran(0.0, 3e-7, tran_opts(**kw))
+        assert rc0 == 0 and st0["stepper"] == 2, (rc0, e.ctx.last_error())
+        e.ctx.poison_lds()
+        rc1, t1, v1, _, st1 = e.tran(0.0, 3e-7, tran_opts(**kw))
+        assert rc1 == 0 and st1["stepper"] == 2, (rc1, e.ctx.last_error())
+        assert (st1["naccept"], st1["nreject"], st1["nnonliniter"]) == (st0["naccept"], st0["nreject"], st0["nnonliniter"])
+        assert np.array_equal(t0, t1) and np.array_equal(v0, v1)
