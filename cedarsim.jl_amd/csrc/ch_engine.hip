@@ -115,6 +115,38 @@ void source_breakpoints(const HSource& s, const double* par, double t0, double t
   }
 }
 
+// Does the source VALUE jump at t, or is t only a corner (slope discontinuity)?  Same rule as oracle.cpp source_jumps_at.
+bool source_jumps_at(const HSource& s, const double* par, double t) {
+  double amp = 0.0;
+  if (s.kind == CH_SRC_PWL) for (double y : s.ys) amp = std::max(amp, std::fabs(y));
+  else if (s.kind == CH_SRC_PULSE) amp = std::max(std::fabs(par[0]), std::fabs(par[1]));
+  else if (s.kind == CH_SRC_SIN) amp = std::fabs(par[0]) + std::fabs(par[1]);
+  const double a = source_value(s, par, 0.0, std::nextafter(t, -INFINITY), 1), b = source_value(s, par, 0.0, t, 1);
+  return std::fabs(a - b) > 1e-9 * amp;
+}
+
+// (time, code) of one source's break points in (t0, t1): code < 0 = the value jumps, else the length of the segment that starts there
+void source_breakpoint_codes(const HSource& s, const double* par, double t0, double t1, std::vector<std::pair<double, double>>& out) {
+  static const bool restart_all = std::getenv("CEDARHIP_BP_RESTART_ALL") != nullptr;   // the policy of rounds 1-2 (A/B switch)
+  std::vector<double> own;
+  source_breakpoints(s, par, t0, t1, own);
+  std::sort(own.begin(), own.end());
+  for (size_t j = 0; j < own.size(); ++j) {
+    const double seg = (j + 1 < own.size() ? own[j + 1] : t1) - own[j];
+    out.emplace_back(own[j], (restart_all || source_jumps_at(s, par, own[j])) ? -1.0 : seg);
+  }
+}
+// sorted unique times with merged codes (a jump wins, otherwise the shortest segment); t1 closes the list
+void merge_breakpoints(std::vector<std::pair<double, double>>& pts, double t1, std::vector<double>& bps, std::vector<double>& bpc) {
+  pts.emplace_back(t1, -1.0);
+  std::sort(pts.begin(), pts.end());
+  bps.clear(); bpc.clear();
+  for (const auto& pt : pts) {
+    if (!bps.empty() && bps.back() == pt.first) { bpc.back() = (bpc.back() < 0 || pt.second < 0) ? -1.0 : std::min(bpc.back(), pt.second); continue; }
+    bps.push_back(pt.first); bpc.push_back(pt.second);
+  }
+}
+
 // variable-coefficient BDF helpers: tau[0] = t_new, tau[1..] history (newest first)
 void bdf_coeffs(const double* tau, int k, double* alpha) {
   double a0 = 0;
@@ -1155,7 +1187,8 @@ struct ch_circuit {
   // dcm != nullptr: the operating point of the bordered form instead of a transient (PersistArgs::dc_mode) — the state in ring
   // slot 0 is the initial iterate and receives the result; no rows, no finish_tran; returns the solve's status
   int tran_persistent(double t0, double t1, const ch_tran_opts& o, ch_result& R, const std::vector<double>& bps, int kmax, double dtmin, double dtmax,
-                      int max_steps, int nmaxit, hclock::time_point tstart, bool& used, const ch_dc_opts* dcm = nullptr, long long* dc_iters = nullptr) {
+                      int max_steps, int nmaxit, hclock::time_point tstart, bool& used, const ch_dc_opts* dcm = nullptr, long long* dc_iters = nullptr,
+                      const std::vector<double>* bpc = nullptr) {
     used = false;
     hipStream_t st = ctx->stream;
     g_arena = &arena;
@@ -1218,12 +1251,14 @@ struct ch_circuit {
         if (!build_blob(kn, ds, bi, bd, need)) { set_err("device-resident stepper: a workgroup's blocks reference more than 64 sources / known nodes"); return CH_OK; }
         for (size_t q = 0; q < kn.size(); ++q) wgk[(size_t)w * P_MAXSRC + q] = kn[q];
         for (size_t q = 0; q < ds.size(); ++q) wgk[(size_t)w * P_MAXSRC + kn.size() + q] = ds[q];
-        std::vector<double> wb;
-        for (int i : need) source_breakpoints(src[i], &h_src_par[(size_t)i * CH_SRC_NPAR], t0, t1, wb);
-        wb.push_back(t1);
-        std::sort(wb.begin(), wb.end()); wb.erase(std::unique(wb.begin(), wb.end()), wb.end());
+        std::vector<double> wb, wc;
+        { std::vector<std::pair<double, double>> pts;
+          for (int i : need) source_breakpoint_codes(src[i], &h_src_par[(size_t)i * CH_SRC_NPAR], t0, t1, pts);
+          merge_breakpoints(pts, t1, wb, wc); }
         wgc.insert(wgc.end(), {(int)ci.size(), (int)cd.size(), (int)bi.size(), (int)bd.size(), (int)bps_all.size(), (int)wb.size()});
-        ci.insert(ci.end(), bi.begin(), bi.end()); cd.insert(cd.end(), bd.begin(), bd.end()); bps_all.insert(bps_all.end(), wb.begin(), wb.end());
+        ci.insert(ci.end(), bi.begin(), bi.end()); cd.insert(cd.end(), bd.begin(), bd.end());
+        bps_all.insert(bps_all.end(), wb.begin(), wb.end());
+        bps_all.insert(bps_all.end(), wc.begin(), wc.end());   // the codes of these times follow them (the kernel reads code i at [count + i])
         max_ci = std::max(max_ci, bi.size()); max_cd = std::max(max_cd, bd.size());
       }
     }
@@ -1239,7 +1274,11 @@ struct ch_circuit {
     else max_rows = std::min<long long>((long long)max_steps + 2, std::max<long long>(1024, std::min<long long>(1 << 20, (long long)((256u << 20) / (row_d * sizeof(double))))));
     if (o.n_saveat == 0 && std::getenv("CEDARHIP_PERSIST_MAXROWS")) max_rows = std::max(2L, std::atol(std::getenv("CEDARHIP_PERSIST_MAXROWS")));   // test hook: forces the drain-and-resume path
     if (dcm) max_rows = 2;
-    HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); HIPCHK(d_pbps.upload(wg_consts ? bps_all : bps, st));
+    HIPCHK(d_pci.upload(ci, st)); HIPCHK(d_pcd.upload(cd, st)); {
+      std::vector<double> bpu = wg_consts ? bps_all : bps;   // [times | codes]
+      if (!wg_consts) for (size_t b = 0; b < bps.size(); ++b) bpu.push_back(bpc ? (*bpc)[b] : -1.0);
+      HIPCHK(d_pbps.upload(bpu, st));
+    }
     if (wg_consts) { HIPCHK(d_pwgc.upload(wgc, st)); HIPCHK(d_pwgk.upload(wgk, st)); }
     { std::vector<double> sv(o.saveat, o.saveat + std::max(0, o.n_saveat)); if (sv.empty()) sv.push_back(0.0); HIPCHK(d_psave.upload(sv, st)); }
     HIPCHK(d_ptimes.alloc((size_t)2 * max_rows)); /* [times | dense-output point counts] */ HIPCHK(d_prows.alloc((size_t)max_rows * row_d));
@@ -1511,13 +1550,20 @@ struct ch_circuit {
     htime[0] = t0;
     dc_device_ms = device_ms; dc_launches = n_launch; dc_timed = n_timed;   // everything so far was initialisation
 
-    // break points of every sample's sources
-    std::vector<double> bps;
-    { const int nsrc = (int)src.size(); for (int s = 0; s < Ssrc; ++s) for (int i = 0; i < nsrc; ++i) source_breakpoints(src[i], &h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR], t0, t1, bps); }
-    bps.push_back(t1);
-    std::sort(bps.begin(), bps.end());
-    bps.erase(std::unique(bps.begin(), bps.end()), bps.end());
+    // break points of every sample's sources, each with its code: < 0 = some source VALUE jumps there (the integrator restarts at order 1
+    // behind it); >= 0 = a continuous corner (landed on exactly, stepped over with the history kept — IDA's treatment of `tstops`,
+    // src/spectre_env.jl:71-77) and the code is the length of the shortest source segment that starts there (the first step behind
+    // the corner is capped at a tenth of it).  A source is asked only about its own times: linear in the number of points.
+    std::vector<double> bps, bpc;
+    {
+      const int nsrc = (int)src.size();
+      std::vector<std::pair<double, double>> pts;
+      for (int s = 0; s < Ssrc; ++s) for (int i = 0; i < nsrc; ++i) source_breakpoint_codes(src[i], &h_src_par[((size_t)s * nsrc + i) * CH_SRC_NPAR], t0, t1, pts);
+      merge_breakpoints(pts, t1, bps, bpc);
+    }
     size_t ibp = 0;
+    // every transient starts its blocks' LU pivot orders from the identity (see ch_persist.hpp: identical blocks stay identical)
+    if (d_perm.p) HIPCHK(hipMemsetAsync(d_perm.p, 0, (size_t)A.n_comp * S * 16, ctx->stream));
 
     // ---- device-resident step controller (ch_persist.hpp) where the circuit qualifies ----
     {
@@ -1529,7 +1575,7 @@ struct ch_circuit {
         if (persist_eligible(why, persist_own_steps(o))) {
           bool used = false;
           persist_aborted = false;
-          rc = tran_persistent(t0, t1, o, R, bps, kmax, dtmin, dtmax, max_steps, nmaxit, tstart, used);
+          rc = tran_persistent(t0, t1, o, R, bps, kmax, dtmin, dtmax, max_steps, nmaxit, tstart, used, nullptr, nullptr, &bpc);
           if (used && persist_aborted && want != CH_STEPPER_DEVICE) {
             // A grid-wide wait ran into its bound: the cooperative launch shared the GPU with another process's kernel and
             // its workgroups were not all resident.  The solve is repeated on the host stepper (whose launches need no
@@ -1589,6 +1635,8 @@ struct ch_circuit {
     for (int step = 0; step < max_steps && t < t1;) {
       while (ibp < bps.size() && bps[ibp] <= t * (1 + 1e-15) + 1e-300) ++ibp;
       const double tb = ibp < bps.size() ? bps[ibp] : t1;
+      const double tb_code = ibp < bps.size() ? bpc[ibp] : -1.0;
+      const bool tb_jump = tb_code < 0;
       bool hit_bp = false;
       double tn = t + h;
       if (tn >= tb - 1e-3 * h) { tn = tb; hit_bp = true; }
@@ -1658,7 +1706,11 @@ struct ch_circuit {
       if (best > 1.0 && best < 1.2) best = 1.0;  // dead band: keep h when the suggested change is small
       h = std::min(dtmax, hh * std::min(kk == 1 ? 10.0 : 2.0, std::max(0.5, best)));
       t = tn;
-      if (hit_bp && t < t1) {
+      if (hit_bp && t < t1 && !tb_jump) {   // continuous corner: history and order are kept, the first step behind it is capped (oracle.cpp)
+        reset_rate = true;
+        h = std::max(dtmin * 10, std::min(h, tb_code / 10.0));
+      }
+      if (hit_bp && t < t1 && tb_jump) {
         nhist = 1; k = 1; steps_at_order = 0; reset_rate = true;
         double nb = t1;
         for (size_t b = ibp; b < bps.size(); ++b) if (bps[b] > t * (1 + 1e-15)) { nb = bps[b]; break; }

@@ -59,7 +59,7 @@ struct PersistArgs {
   int wave_doubles;           // LDS doubles per wave region
   double t1, dtmin, dtmax, first_frac;
   int kmax, max_steps, nbp, n_saveat;
-  const double* bps; const double* saveat;
+  const double* bps; const double* saveat;   // bps: [nbp times | nbp codes (< 0: the sources jump there; else the length of the source segment starting there)]; per workgroup the same pair at its offset
   const int* ci; const double* cd; int n_ci, n_cd;   // constants blob (sources, known-node definitions), copied to LDS
   // per-block steps of ONE circuit: a blob per workgroup with the sources of its own blocks only.  wgc[6 wg ..] = {ci offset,
   // cd offset, n_ci, n_cd, break-point offset, break-point count}; n_ci / n_cd above are then the largest sizes (LDS layout);
@@ -508,8 +508,11 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   double rate_prev = 1.0;
   // pivot order of the block's register LU (lu_solve_block): lane i loads row myrow; kept for the whole transient, and across
   // launches / step controllers through a.perm (row ^ lane per unknown, 0 = identity)
+  // A transient starts from the identity (the pivot order is then a function of the block's own history alone: identical blocks —
+  // the tiles of an array, equal samples of a batch — stay bit-identical whatever the operating-point search did to each of them);
+  // a relaunch of the same transient (drained row buffer) continues with the order it had.
   int myrow = lane;
-  if (MODE != PM_BORDER && a.perm && mine) myrow = lane ^ (int)a.perm[(long)blk * 16 + lane];
+  if (MODE != PM_BORDER && a.perm && mine && p.resume) myrow = lane ^ (int)a.perm[(long)blk * 16 + lane];
   lds_fence();
   __syncthreads();
 
@@ -541,6 +544,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   const double e_c0 = e_nt > 0 ? C.ent_coef()[e_p0] : 0.0, e_c1 = e_nt > 1 ? C.ent_coef()[e_p0 + 1] : 0.0;
   double s0_lo = __builtin_inf(), s0_hi = -__builtin_inf(), s0_y = 0.0, s0_m = 0.0, s1_lo = __builtin_inf(), s1_hi = -__builtin_inf(), s1_y = 0.0, s1_m = 0.0;
   double bp_next = 0.0; int bp_at = -1;        // cached p.bps[ibp]
+  double bp_code = -1.0;                       // ... and its code: < 0 the sources JUMP there (restart at order 1); >= 0 a continuous corner, the
+                                               //     length of the source segment that starts there
   double sv_next = 0.0; int sv_at = -1;        // cached p.saveat[isave]
   const long long row_stride = (long long)p.n_obs * a.S;
   const int my_ob = mine ? (dml[lane] >> 8) - 1 : -1;
@@ -571,7 +576,7 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     asm volatile("" : "+v"(ln));
     // next break point: global loads only when the index moves
     for (;;) {
-      if (bp_at != ibp) { bp_next = ibp < P_NBP ? P_BPS[ibp] : p.t1; bp_at = ibp; }
+      if (bp_at != ibp) { bp_next = ibp < P_NBP ? P_BPS[ibp] : p.t1; bp_code = ibp < P_NBP ? P_BPS[P_NBP + ibp] : -1.0; bp_at = ibp; }
       if (ibp < P_NBP && bp_next <= t * (1 + 1e-15) + 1e-300) ++ibp; else break;
     }
     const double tb = bp_next;
@@ -1038,10 +1043,15 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
     h = fmin(p.dtmax, hh * fmin(kk == 1 ? 10.0 : 2.0, fmax(0.5, best)));
     t = tn;
     if (hit_bp && t < p.t1) {
-      nhist = 1; k = 1; steps_at_order = 0; reset_rate = true;
-      double nb = p.t1;
-      for (int b = ibp; b < P_NBP; ++b) if (P_BPS[b] > t * (1 + 1e-15)) { nb = P_BPS[b]; break; }
-      h = fmax(p.dtmin * 10, fmin(h, (nb - t) / 50.0) * p.first_frac);
+      // behind a JUMP of a source: restart at order 1 with a tiny first step; at a continuous corner (IDA's tstops) history and order
+      // are kept and the first step is capped at a tenth of the source segment that starts there (same policy as ch_circuit::tran_solve)
+      reset_rate = true;
+      if (bp_code < 0) {
+        nhist = 1; k = 1; steps_at_order = 0;
+        double nb = p.t1;
+        for (int b = ibp; b < P_NBP; ++b) if (P_BPS[b] > t * (1 + 1e-15)) { nb = P_BPS[b]; break; }
+        h = fmax(p.dtmin * 10, fmin(h, (nb - t) / 50.0) * p.first_frac);
+      } else h = fmax(p.dtmin * 10, fmin(h, bp_code * 0.1));
     }
     P_STAMP(11);  // controller, saved rows
   }

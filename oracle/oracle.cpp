@@ -115,6 +115,18 @@ static double source_value(const Source& s, double t, int mode) {
   }
   return 0.0;
 }
+// Does the source VALUE jump at t (left limit != value at t), or is t only a corner (slope discontinuity)?  The integrator
+// restarts at order 1 only behind a jump; a continuous corner is landed on exactly and stepped over with the history kept
+// (what IDA does with `tstops`: src/spectre_env.jl:71-77 only announces the times).  A corner so steep that the two values differ
+// by rounding alone is taken for a jump: that is the old, always safe behaviour.
+static bool source_jumps_at(const Source& s, double t) {
+  double amp = 0.0;
+  if (s.kind == CH_SRC_PWL) for (double y : s.ys) amp = std::max(amp, std::fabs(y));
+  else if (s.kind == CH_SRC_PULSE) amp = std::max(std::fabs(s.par[0]), std::fabs(s.par[1]));
+  else if (s.kind == CH_SRC_SIN) amp = std::fabs(s.par[0]) + std::fabs(s.par[1]);
+  const double a = source_value(s, std::nextafter(t, -INFINITY), 1), b = source_value(s, t, 1);
+  return std::fabs(a - b) > 1e-9 * amp;
+}
 // break points inside (t0, t1] — what time_periodic_singularities! announces (spectre_env.jl:71-77)
 static void source_breakpoints(const Source& s, double t0, double t1, std::vector<double>& out) {
   if (s.kind == CH_SRC_PWL) {
@@ -471,11 +483,30 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
     else if (d.kind == CH_DEV_VA) { const va_gen::ModuleInfo& mi = va_gen::MODULES[d.ipar[0]]; for (int k = 0; k < mi.n_nodes; ++k) if (mi.q_mask & (1u << k)) mark(d.node[k]); }
   }
 
-  std::vector<double> bps;
-  for (const Source& s : c.src) source_breakpoints(s, t0, t1, bps);
-  bps.push_back(t1);
-  std::sort(bps.begin(), bps.end());
-  bps.erase(std::unique(bps.begin(), bps.end()), bps.end());
+  // break points with their kind: bpc[i] < 0: some source VALUE jumps there (restart at order 1 behind it); bpc[i] >= 0: a continuous
+  // corner, and bpc[i] is the length of the shortest source segment that starts there (the first step behind the corner is capped
+  // at a tenth of it).  A source is asked only about its own times.
+  std::vector<double> bps, bpc;
+  {
+    const bool restart_all = std::getenv("CEDARHIP_BP_RESTART_ALL") != nullptr;   // the policy of rounds 1-2, for A/B comparisons
+    std::vector<std::pair<double, double>> pts;
+    std::vector<double> own;
+    for (const Source& s : c.src) {
+      own.clear();
+      source_breakpoints(s, t0, t1, own);
+      std::sort(own.begin(), own.end());
+      for (size_t j = 0; j < own.size(); ++j) {
+        const double seg = (j + 1 < own.size() ? own[j + 1] : t1) - own[j];
+        pts.emplace_back(own[j], (restart_all || source_jumps_at(s, own[j])) ? -1.0 : seg);
+      }
+    }
+    pts.emplace_back(t1, -1.0);
+    std::sort(pts.begin(), pts.end());
+    for (const auto& pt : pts) {
+      if (!bps.empty() && bps.back() == pt.first) { bpc.back() = (bpc.back() < 0 || pt.second < 0) ? -1.0 : std::min(bpc.back(), pt.second); continue; }
+      bps.push_back(pt.first); bpc.push_back(pt.second);
+    }
+  }
   size_t ibp = 0;
 
   auto obs_of = [&](const std::vector<double>& xs, int k) {
@@ -518,6 +549,8 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
     // clip to next break point
     while (ibp < bps.size() && bps[ibp] <= t * (1 + 1e-15) + 1e-300) ++ibp;
     double tb = ibp < bps.size() ? bps[ibp] : t1;
+    const double tb_code = ibp < bps.size() ? bpc[ibp] : -1.0;
+    const bool tb_jump = tb_code < 0;
     bool hit_bp = false;
     double tn = t + h;
     if (tn >= tb - 1e-3 * h) { tn = tb; hit_bp = true; }
@@ -688,8 +721,15 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
     hist.insert(hist.begin(), HistPoint{tn, xn, qn});
     if ((int)hist.size() > kmax + 2) hist.pop_back();
     t = tn;
-    if (hit_bp && t < t1) {
-      // slope discontinuity: restart at order 1 from this point
+    if (hit_bp && t < t1 && !tb_jump) {
+      // continuous corner: history and order are kept; the slope of a source has changed, so the first step behind the corner is
+      // capped at a tenth of that source's new segment (without the cap it is the old step size, and the Newton iteration from a
+      // predictor that knows nothing of the new slope fails there: 7 failures per DFF transient, none with it)
+      newton_rate = 1.0;
+      h = std::max(dtmin * 10, std::min(h, tb_code / 10.0));
+    }
+    if (hit_bp && t < t1 && tb_jump) {
+      // the sources jump here: restart at order 1 from this point
       hist.resize(1);
       k = 1; steps_at_order = 0; newton_rate = 1.0;
       double nb = t1;

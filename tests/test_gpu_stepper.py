@@ -391,3 +391,49 @@ def test_waves_without_a_block_never_read_unstaged_lds(E):
         assert rc1 == 0 and st1["stepper"] == 2, (rc1, e.ctx.last_error())
         assert (st1["naccept"], st1["nreject"], st1["nnonliniter"]) == (st0["naccept"], st0["nreject"], st0["nnonliniter"])
         assert np.array_equal(t0, t1) and np.array_equal(v0, v1)
+
+
+def test_continuous_corners_keep_the_history_jumps_restart(E, O):
+    """Break-point policy (IDA `tstops`, src/spectre_env.jl:71-77): every break point is landed on exactly; behind a JUMP of a source
+    value the integrator restarts at order 1, at a continuous corner (a PWL knee) it keeps its history and order and only caps the
+    next step.  Eight tiles with private, skewed clocks in ONE step sequence (lock-step, every step saved) have 96 private corners:
+    with the restart at every corner (CEDARHIP_BP_RESTART_ALL=1, the policy of rounds 1-2) each costs about five steps.  Checked:
+    fewer steps, both step controllers and the oracle agree on the waveform, and a PWL with a true jump still restarts (the capacitor
+    integrates the jump exactly: test_gpu_parity_wide covers the values; here the step counts show the restart)."""
+    rng = np.random.default_rng(1234)
+    ckt = dff_array(8, skew=rng.uniform(0.0, 50e-12, 8), observe="q")
+    e, o = E(ckt), O(ckt)
+    rc, xo, _ = o.dc(dc_opts(abstol=1e-14))
+    assert rc == 0
+    kw = dict(abstol=1e-5, reltol=1e-5, skip_dc=True)
+    res = {}
+    for label, env, stepper in (("device", None, "device"), ("host", None, "host"), ("device_restart_all", "1", "device")):
+        if env:
+            os.environ["CEDARHIP_BP_RESTART_ALL"] = env
+        try:
+            rcx, t, v, _, st = e.tran(0.0, 7e-7, tran_opts(stepper=stepper, dc=dc_opts(x0=xo[None, :]), **kw))
+        finally:
+            os.environ.pop("CEDARHIP_BP_RESTART_ALL", None)
+        assert rcx == 0, (label, rcx, e.ctx.last_error())
+        res[label] = (t, v, st)
+    st_d, st_h, st_r = res["device"][2], res["host"][2], res["device_restart_all"][2]
+    assert st_d["stepper"] == 2 and st_d["stepper_mode"] == 1 and st_h["stepper"] == 1
+    assert (st_d["naccept"], st_d["nreject"]) == (st_h["naccept"], st_h["nreject"])          # one policy, two controllers
+    assert st_d["naccept"] < 0.75 * st_r["naccept"], (st_d["naccept"], st_r["naccept"])     # 96 corners no longer cost a restart each
+    t, v, _ = res["device"]
+    keep = np.concatenate(([True], np.diff(t) > 0))
+    rco, to, vo, _, sto = o.tran(0.0, 7e-7, tran_opts(saveat=t[keep], dc=dc_opts(x0=xo), **kw))
+    assert rco == 0 and np.max(np.abs(v[:, keep, 0] - vo)) < 2e-3       # same policy in the oracle; tolerance-level agreement of two solvers
+    for tt, q in zip(DFF_CHECK_TIMES, DFF_CHECK_Q):
+        assert np.max(np.abs([np.interp(tt, t, v[k, :, 0]) - q for k in range(8)])) < 1e-3
+    # a source with a true jump: the step right behind it is the tiny restart step
+    c = Circuit()
+    c.V("v1", "a", 0, tran=PWL([0.0, 0.0, 1e-9, 0.0, 1e-9, 1.0, 2e-9, 1.0, 3e-9, 0.0, 5e-9, 0.0]))   # jump at 1 ns, knees at 2 and 3 ns
+    c.R("r1", "a", "b", 1e3)
+    c.C("c1", "b", 0, 1e-12)
+    c.observe_node("b")
+    ej = E(c)
+    rcj, tj, vj, _, stj = ej.tran(0.0, 5e-9, tran_opts(abstol=1e-9, reltol=1e-6, stepper="device"))
+    assert rcj == 0
+    after = lambda tb: tj[np.searchsorted(tj, tb, side="right")] - tb          # noqa: E731  first step behind a break point
+    assert after(1e-9) < 1e-13 and after(2e-9) > 1e-12 and after(3e-9) > 1e-12, (after(1e-9), after(2e-9), after(3e-9))
