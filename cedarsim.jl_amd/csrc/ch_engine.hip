@@ -127,7 +127,7 @@ bool source_jumps_at(const HSource& s, const double* par, double t) {
 
 // (time, code) of one source's break points in (t0, t1): code < 0 = the value jumps, else the length of the segment that starts there
 void source_breakpoint_codes(const HSource& s, const double* par, double t0, double t1, std::vector<std::pair<double, double>>& out) {
-  static const bool restart_all = std::getenv("CEDARHIP_BP_RESTART_ALL") != nullptr;   // the policy of rounds 1-2 (A/B switch)
+  const bool restart_all = std::getenv("CEDARHIP_BP_RESTART_ALL") != nullptr;   // the policy of rounds 1-2 (A/B switch; read per call: the tests flip it)
   std::vector<double> own;
   source_breakpoints(s, par, t0, t1, own);
   std::sort(own.begin(), own.end());
@@ -254,6 +254,7 @@ struct ch_circuit {
   DevBuf<BlockMeta> d_bmeta;
   std::vector<ClassMeta> h_cms;
   int block_threads = 64, lu_variant = 16, max_mc = 0;
+  bool wide_split = false; int wide_l = 0, wide_other = 0;   // class 0: its large compiled devices are evaluated in two halves; lanes per half; unsplit slots
   bool host_reduce = true;      // block outputs land in mapped host memory and the host reduces them
   BlockOut* h_out = nullptr;    // mapped pinned [n_comp*S]
   size_t h_out_n = 0;
@@ -360,6 +361,7 @@ struct ch_circuit {
           for (int j = 0; j < e.nt; ++j) if (e.term[j] >= 0) { lanes.push_back((d << 4) | (first ? 8 : 0) | j); first = false; }
         }
         const bool split = big && std::getenv("CEDARHIP_VA_NOSPLIT") == nullptr;
+        if (ci == 0) { wide_split = split; wide_l = (int)lanes.size(); wide_other = 0; }
         if (!split) { for (int v : lanes) { blob.push_back(v); ++ns; } }
         else {
           for (int v : lanes) { blob.push_back(v | (1 << 29)); ++ns; }
@@ -367,8 +369,8 @@ struct ch_circuit {
           for (int v : lanes) { blob.push_back(v | (1 << 29) | (1 << 30)); ++ns; }
         }
       }
-      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind == K_MOS) { blob.push_back(d << 4); ++ns; }
-      for (int d = 0; d < c.ndev; ++d) { const int kd = A.edev[A.comp_dofs[rep] + d].kind; if (kd != K_MOS && kd != K_VA) { blob.push_back(d << 4); ++ns; } }
+      for (int d = 0; d < c.ndev; ++d) if (A.edev[A.comp_dofs[rep] + d].kind == K_MOS) { blob.push_back(d << 4); ++ns; if (ci == 0) ++wide_other; }
+      for (int d = 0; d < c.ndev; ++d) { const int kd = A.edev[A.comp_dofs[rep] + d].kind; if (kd != K_MOS && kd != K_VA) { blob.push_back(d << 4); ++ns; if (ci == 0) ++wide_other; } }
       m.nslots = ns;
       std::vector<uint16_t> h16(c.mat_src); h16.insert(h16.end(), c.vec_src.begin(), c.vec_src.end());
       if (h16.size() & 1) h16.push_back(0);
@@ -1156,29 +1158,44 @@ struct ch_circuit {
     auto no = [&](const char* m) { why = m; return false; };
     if (path != 1) return no("the circuit takes the sparse path");
     if (A.n_comp < 1) return no("the circuit has no unknowns");
-    if (A.wide) return no("compiled Verilog-A devices (wide stamp records)");
     if (!(lu_variant == 8 || lu_variant == 12 || lu_variant == 16)) return no("a Jacobian block has more than 16 unknowns");
-    if (block_threads != 64 || max_mc > 8) return no("a block needs more than one wavefront of device slots or more than 8 MOSFET classes");
+    if (A.wide) {
+      // compiled Verilog-A devices: every block of ONE class; a class with split (large) devices needs both halves of two blocks in
+      // one wavefront each (wave pairs), any other class all its slots in one wavefront
+      if (A.classes.size() != 1) return no("compiled Verilog-A devices in blocks of several classes");
+      if (A.nb > 0) return no("compiled Verilog-A devices in a bordered form");
+      if (wide_split ? (wide_l + wide_other > 32) : (h_cms[0].nslots > 64)) return no("a block's compiled devices need more evaluation lanes than a wave pair offers");
+      if (own_steps && S == 1 && A.n_comp > 1) return no("per-block steps of one circuit with compiled Verilog-A devices");
+    } else if (block_threads != 64) return no("a block needs more than one wavefront of device slots");
+    if (max_mc > 8) return no("more than 8 MOSFET classes in a block");
     if (Ssrc != 1) return no("per-sample source parameters");
     const bool wg_consts = own_steps && S == 1 && A.n_comp > 1;   // per-block steps: every workgroup gets the sources of ITS blocks only (checked there)
     if (!wg_consts && (needed_src.size() > (size_t)P_MAXSRC || A.known.size() + (size_t)n_dev_src() > 64)) return no("more than 64 sources / known-node and source values per attempt");
     if (!(S == 1 || A.n_comp == 1)) return no("several blocks per sample in a multi-sample batch");
     if (A.nb > 0 && (S != 1 || A.border_dev.size() > 8)) return no("bordered form: one sample and at most 8 devices on the border alone");
-    for (const ClassMeta& m : h_cms) if (m.nslots > 64 || m.nc > lu_variant || m.n_work <= 0) return no("a block class does not fit the one-wave register path");
+    for (const ClassMeta& m : h_cms) if ((!A.wide && m.nslots > 64) || m.nc > lu_variant || m.n_work <= 0) return no("a block class does not fit the one-wave register path");
     if (n_cu == 0) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return no("hipGetDeviceProperties failed"); n_cu = prop.multiProcessorCount; }
     const long nblk = (long)A.n_comp * S;
-    if (nblk > (long)PW * n_cu && !own_steps) return no("more blocks than resident wavefronts (4 per CU)");
+    const int bpw = persist_bpw(nblk);
+    if (nblk > (long)bpw * n_cu && !own_steps) return no("more blocks than resident wavefronts (4 per CU)");
     // p_grid_reduce: 8 group leaders sweep at most 32 member workgroups each
-    if (!own_steps && (nblk + PW - 1) / PW > 256) return no("more than 256 workgroups in a grid-wide reduction");
+    if (!own_steps && (nblk + bpw - 1) / bpw > 256) return no("more than 256 workgroups in a grid-wide reduction");
     size_t npwl = 0; for (int i : needed_src) npwl += src[i].ts.size();
     if (!wg_consts && npwl > 2048) return no("piecewise-linear tables above 2048 points");
     return true;
+  }
+  // Blocks per workgroup of the device-resident stepper: four (one per wavefront), or two — one wave pair per CU, the other two
+  // wavefronts idle — for few, heavy blocks (compiled Verilog-A devices: 57 k instructions per evaluation and a 5 kB constant block
+  // per instance): they then spread over twice the CUs and do not share a CU's vector L1 four ways.
+  int persist_bpw(long nblk) const {
+    if (n_cu > 0 && A.wide && wide_split && nblk <= 2L * n_cu) return 2;
+    return PW;
   }
   // Every sample of a batch (n_comp == 1) or every block of one circuit of independent blocks (S == 1) takes its own steps when
   // the output is wanted on a common `saveat` grid: independent blocks ARE independent problems, a shared step size only makes
   // each pay for the others' break points and dilutes its local error in the array-wide norm.  (Not for the bordered form.)
   bool persist_own_steps(const ch_tran_opts& o) const {
-    return ((A.n_comp == 1 && S > 1) || (S == 1 && A.n_comp > 1 && A.nb == 0)) && o.n_saveat > 0 && std::getenv("CEDARHIP_LOCKSTEP") == nullptr;
+    return ((A.n_comp == 1 && S > 1) || (S == 1 && A.n_comp > 1 && A.nb == 0 && !A.wide)) && o.n_saveat > 0 && std::getenv("CEDARHIP_LOCKSTEP") == nullptr;
   }
   size_t persist_wave_doubles(bool wg_consts) const {
     const size_t n_ent = wg_consts ? (size_t)P_MAXSRC : A.known.size() + n_dev_src();
@@ -1193,7 +1210,7 @@ struct ch_circuit {
     hipStream_t st = ctx->stream;
     g_arena = &arena;
     const int n_obs = R.n_obs;
-    const int nblk = A.n_comp * S, n_wg = (nblk + PW - 1) / PW;
+    const int nblk = A.n_comp * S, bpw = persist_bpw(nblk), n_wg = (nblk + bpw - 1) / bpw;
     // ---- constants blob: needed sources, known-node definitions, device-source map, PWL tables ----
     // One blob for the whole grid, or — per-block steps of one circuit (wg_consts) — one per workgroup holding only what its
     // blocks reference, with a map from the circuit's known-node / device-source indices to the workgroup's entries: a block with
@@ -1238,7 +1255,7 @@ struct ch_circuit {
       wgk.assign((size_t)n_wg * P_MAXSRC, -1);   // [wg][entry]: known-node index (entries 0 .. nk_local-1), then device-source slot
       for (int w = 0; w < n_wg; ++w) {
         std::vector<char> uk(nk, 0), ud(nds, 0);
-        for (int b = w * PW; b < std::min(nblk, (w + 1) * PW); ++b)
+        for (int b = w * bpw; b < std::min(nblk, (w + 1) * bpw); ++b)
           for (int i = 0; i < A.comp_ndev[b]; ++i) {
             const EDev& e = A.edev[A.comp_dofs[b] + i];
             for (int k = 0; k < NTERM; ++k) if (e.term[k] < 0) uk[-e.term[k] - 1] = 1;
@@ -1265,7 +1282,8 @@ struct ch_circuit {
     const size_t wave_d = persist_wave_doubles(wg_consts);
     const size_t lds = (max_cd + (max_ci + 1) / 2 + PW * P_NREC + P_NREC + 4 + P_SCR + PW * wave_d) * sizeof(double);
     // wave pairs share the device evaluation by function when every block has the same class and at most 32 evaluation slots
-    const bool pair = A.classes.size() == 1 && h_cms[0].nslots <= 32 && std::getenv("CEDARHIP_PERSIST_NOPAIR") == nullptr;
+    const bool pair = A.wide ? wide_split
+                             : (A.classes.size() == 1 && h_cms[0].nslots <= 32 && std::getenv("CEDARHIP_PERSIST_NOPAIR") == nullptr);
     if (lds > 150 * 1024) { set_err("device-resident stepper: the workgroup's LDS footprint exceeds 150 KB"); return CH_OK; }
     // ---- output rows ----
     const size_t row_d = std::max<size_t>(1, (size_t)n_obs * S);
@@ -1286,6 +1304,7 @@ struct ch_circuit {
     PersistArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.a = base;
     pa.a.mode = MODE_TRAN; pa.a.maxit = nmaxit; pa.a.abstol = o.abstol; pa.a.reltol = o.reltol; pa.a.newton_tol = 0.1; pa.a.active = nullptr; pa.a.gshunt = 0.0;
+    pa.bpw = bpw; pa.wide_l = wide_l; pa.wide_other = wide_other;
     pa.nblk = nblk; pa.n_wg = n_wg; pa.red_max = (S > 1 || own_steps) ? 1 : 0; pa.wave_doubles = (int)wave_d;
     pa.t1 = t1; pa.dtmin = dtmin; pa.dtmax = dtmax; pa.first_frac = 1e-3; pa.kmax = kmax; pa.max_steps = max_steps;
     pa.bps = d_pbps.p; pa.nbp = (int)bps.size(); pa.saveat = d_psave.p; pa.n_saveat = o.n_saveat;
@@ -1323,7 +1342,9 @@ struct ch_circuit {
     double h = o.dt0 > 0 ? o.dt0 : std::min(dtmax, 1e-3 * span);
     h = std::max(10 * dtmin, std::min(h, (bps[0] - t0) / 50.0) * 1e-3);
     cs.t = t0; cs.h = h; cs.k = 1; cs.nhist = 1; cs.reset_rate = 1; cs.tslot[0] = t0;
-    const void* fn = A.nb > 0 ? (pair ? (const void*)tran_persistent_kernel<16, true, PM_BORDER> : (const void*)tran_persistent_kernel<16, false, PM_BORDER>)
+    const void* fn = A.wide ? (own_steps ? (pair ? (const void*)tran_persistent_kernel<16, true, PM_OWN, true> : (const void*)tran_persistent_kernel<16, false, PM_OWN, true>)
+                                         : (pair ? (const void*)tran_persistent_kernel<16, true, PM_LOCKSTEP, true> : (const void*)tran_persistent_kernel<16, false, PM_LOCKSTEP, true>))
+                   : A.nb > 0 ? (pair ? (const void*)tran_persistent_kernel<16, true, PM_BORDER> : (const void*)tran_persistent_kernel<16, false, PM_BORDER>)
                    : own_steps ? (lu_variant <= 12 ? (pair ? (const void*)tran_persistent_kernel<12, true, PM_OWN> : (const void*)tran_persistent_kernel<12, false, PM_OWN>)
                                                    : (pair ? (const void*)tran_persistent_kernel<16, true, PM_OWN> : (const void*)tran_persistent_kernel<16, false, PM_OWN>))
                    : lu_variant <= 12 ? (pair ? (const void*)tran_persistent_kernel<12, true> : (const void*)tran_persistent_kernel<12, false>)

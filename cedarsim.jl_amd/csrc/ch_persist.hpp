@@ -56,6 +56,8 @@ struct TranCtl {
 struct PersistArgs {
   NewtonArgs a;               // structure pointers, tolerances, state ring (read at start, written back at exit)
   int nblk, n_wg, red_max;    // red_max 1: n_comp == 1 (max over samples of the per-sample WRMS); 0: S == 1 (WRMS over all blocks)
+  int bpw;                    // blocks per workgroup: PW, or 2 (one wave pair per CU, the other two waves idle) to spread few, heavy blocks over more CUs
+  int wide_l, wide_other;     // WIDE + PAIR: lanes of one half of the block's split compiled devices, and its other (unsplit) evaluation slots
   int wave_doubles;           // LDS doubles per wave region
   double t1, dtmin, dtmax, first_frac;
   int kmax, max_steps, nbp, n_saveat;
@@ -376,9 +378,12 @@ __device__ __forceinline__ double p_coef(double tau0, const double* tsl, int hea
 // instantiations, so that the lock-step kernel of the headline workload carries none of the others' state (the shared-code
 // versions cost the 1024-DFF array 3 - 8 %).
 enum { PM_LOCKSTEP = 0, PM_OWN = 1, PM_BORDER = 2 };
-template <int NC, bool PAIR, int MODE = PM_LOCKSTEP>
+// WIDE: the circuit holds compiled Verilog-A devices (144-double stamp records, ch_kernels.hpp eval_slot<true>: one lane per unknown
+// terminal and half).  With PAIR the two waves of a pair split every large compiled device of their two blocks by FUNCTION like the
+// BSIM4 halves: wave 2q the resistive halves (and every unsplit slot), wave 2q+1 the charge halves.
+template <int NC, bool PAIR, int MODE = PM_LOCKSTEP, bool WIDE = false>
 __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const PersistArgs p) {
-  typedef StampLayout<false> SL;
+  typedef StampLayout<WIDE> SL;
   extern __shared__ double lds[];
   __shared__ int s_abort;
   __shared__ double s_bdec[4];   // bordered form: the border step and residual every wave of the workgroup decides from
@@ -416,8 +421,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   __syncthreads();
   const PConst C{cil, cdl};
 
-  const int blk = wg * PW + wave;
-  const bool live = blk < p.nblk;
+  const int blk = wg * p.bpw + wave;
+  const bool live = wave < p.bpw && blk < p.nblk;
   const int bq = live ? blk : 0;
   const int c = bq / a.S, s = bq - c * a.S;
   const BlockMeta bm = a.bmeta[c];
@@ -444,8 +449,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   // paired evaluation: lanes 0..31 work on the pair's first block, lanes 32..63 on its second
   const int role = wave & 1, pairq = wave >> 1, half = lane >> 5;
   int* pf = pfl + pairq * 4;
-  const int blk_h = wg * PW + (wave & ~1) + half;
-  const bool live_h = PAIR && blk_h < p.nblk;
+  const int blk_h = wg * p.bpw + (wave & ~1) + half;
+  const bool live_h = PAIR && (wave & ~1) + half < p.bpw && blk_h < p.nblk;
   const int bqh = live_h ? blk_h : 0, c_h = bqh / a.S, s_h = bqh - c_h * a.S;
   const int uofs_h = PAIR ? a.bmeta[c_h].uofs : uofs, dofs_h = PAIR ? a.bmeta[c_h].dofs : dofs;
   double* Wh = summ + P_NREC + 4 + P_SCR + (size_t)((wave & ~1) + half) * p.wave_doubles;   // region of this lane's block (same class, same layout)
@@ -516,10 +521,25 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
   lds_fence();
   __syncthreads();
 
-  const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s : 0], a.vapar, 300.15, nullptr, nullptr};
+  const int s_e = PAIR ? s_h : s;   // the sample of the block this lane evaluates for
+  const EvalCtx ectx{a.dkind, a.dterm, a.dsrc, a.dcls_local, a.dhdev, a.dpar, a.dmult, a.Spar, a.gmin_s[a.Sgmin > 1 ? s_e : 0],
+                     WIDE ? a.vapar + (long)s_e * a.va_stride : a.vapar, WIDE ? a.temp_s[a.Stemp > 1 ? s_e : 0] + 273.15 : 300.15,
+                     WIDE ? a.vacache + (long)s_e * a.vac_stride : nullptr, WIDE ? a.dvac : nullptr};
   // this lane's device for the whole transient (block `half` of the pair when PAIR, the wave's own block otherwise)
   const double gmin_h = a.gmin_s[a.Sgmin > 1 ? (PAIR ? s_h : s) : 0];
   SlotMeta smeta;
+  int wslot = -1;   // WIDE: this lane's evaluation slot (eval_slot<true> reads the device tables itself)
+  if (WIDE) {
+    smeta = load_slot_meta(ectx, 0, 0, 0, -1);   // an idle narrow slot
+    if (PAIR) {
+      // slot list of a class with split devices: [first halves (wide_l) | idle up to 64 | second halves (wide_l) | unsplit slots]
+      const int sq = lane & 31;
+      if (live_h) {
+        if (sq < p.wide_l) wslot = slots_h[role == 0 ? sq : 64 + sq];
+        else if (role == 0 && sq - p.wide_l < p.wide_other) wslot = slots_h[64 + p.wide_l + (sq - p.wide_l)];
+      }
+    } else if (live && lane < cm.nslots) wslot = slots[lane];
+  } else
   {
     int slot = -1;
     if (PAIR) { const int sq = lane & 31; if (live_h && sq < cm.nslots) slot = slots_h[sq]; }
@@ -662,8 +682,11 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
           const int d0 = pf[2], d1 = pf[3];
           if (!bbd && ((d0 && d1) || pair_broken)) break;
           if (!(half ? d1 : d0)) {
+            if (WIDE) { if (wslot >= 0) eval_slot<true>(ectx, s_h, dofs_h, wslot, xl_h, uofs_h, kvl, svl, pl_h, st_h); }
+            else {
             if (role == 0) eval_cached<0>(smeta, gmin_h, xl_h, kvl, svl, pl_h, st_h);
             if (role == 1 ? (p.pair_dbg & 1) == 0 : (p.pair_dbg & 1) == 1) eval_cached<1>(smeta, gmin_h, xl_h, kvl, svl, pl_h, st_h);
+            }
           }
           pair_sync();                                   // both halves of every stamp record are in LDS
           P_STAMP(4);   // device evaluation (one half of it)
@@ -672,7 +695,8 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
             if (done_own) continue;
           }
         } else {
-        if (!bbd || live) eval_cached<-1>(smeta, gmin_h, xl, kvl, svl, pl, st);
+        if (WIDE) { if (wslot >= 0) eval_slot<true>(ectx, s, dofs, wslot, xl, uofs, kvl, svl, pl, st); }
+        else if (!bbd || live) eval_cached<-1>(smeta, gmin_h, xl, kvl, svl, pl, st);
         lds_fence();
         P_STAMP(4);   // device evaluation
         }

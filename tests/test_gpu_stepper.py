@@ -19,6 +19,12 @@ def E():
     return EngineCircuit
 
 
+@pytest.fixture(scope="module")
+def O(oracle_lib):
+    from oracle_binding import Oracle
+    return Oracle
+
+
 def run(e, tspan, stepper, **kw):
     rc, t, v, xf, st = e.tran(tspan[0], tspan[1], tran_opts(stepper=stepper, **kw))
     assert rc == 0, (rc, e.ctx.last_error())
@@ -419,7 +425,7 @@ def test_continuous_corners_keep_the_history_jumps_restart(E, O):
     st_d, st_h, st_r = res["device"][2], res["host"][2], res["device_restart_all"][2]
     assert st_d["stepper"] == 2 and st_d["stepper_mode"] == 1 and st_h["stepper"] == 1
     assert (st_d["naccept"], st_d["nreject"]) == (st_h["naccept"], st_h["nreject"])          # one policy, two controllers
-    assert st_d["naccept"] < 0.75 * st_r["naccept"], (st_d["naccept"], st_r["naccept"])     # 96 corners no longer cost a restart each
+    assert st_d["naccept"] + 2 * 96 <= st_r["naccept"], (st_d["naccept"], st_r["naccept"])   # 96 private corners: each restart cost at least two extra steps
     t, v, _ = res["device"]
     keep = np.concatenate(([True], np.diff(t) > 0))
     rco, to, vo, _, sto = o.tran(0.0, 7e-7, tran_opts(saveat=t[keep], dc=dc_opts(x0=xo), **kw))

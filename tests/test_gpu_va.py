@@ -226,7 +226,7 @@ def test_config5_bsimcmg_asap7_inverter_array(E, O):
     v_o = v_o if v_o.ndim == 3 else v_o[:, :, None]
     assert rc_o == 0
     assert np.allclose(v[0, :, 0], v_o[0, :, 0], rtol=0, atol=1e-4)
-    print("config5: 128 inverters, %d accepted / %d rejected steps, %.3f s wall, %d block iterations" % (st["naccept"], st["nreject"], wall, st["n_block_iters"]))
+    print("config5: 128 inverters, %d accepted / %d rejected steps, %.3f s wall, %d block iterations, stepper %d mode %d" % (st["naccept"], st["nreject"], wall, st["n_block_iters"], st["stepper"], st["stepper_mode"]))
 
 
 def test_sweep_over_verilog_a_parameters_is_batched(E, O):
