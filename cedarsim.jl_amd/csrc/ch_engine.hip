@@ -292,8 +292,11 @@ struct ch_circuit {
   std::vector<double> h_dpar0, h_dmult0;   // main parameter and multiplicity of every device as uploaded (sample 0)
   SparsePlan plan[2];           // [0] DC (alpha0 = 0), [1] transient
   struct PlanDev { DevBuf<int> prow, pcol, a2lu, diag_pos, lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows, lrow_ptr, l_pos, l_k, l_upd_ptr, upd_dst, upd_src, urow_ptr, u_pos, u_col;
-                   DevBuf<int> lu2a, la_pos, la_diag, lb_dst, lb_sptr, lb_l, lb_u, lb_d, fl_rows, bl_rows; DevBuf<double> LUv, Lv; } plan_dev[2];
+                   DevBuf<int> lu2a, la_pos, la_diag, lb_dst, lb_sptr, lb_l, lb_u, lb_d, fl_rows, bl_rows; DevBuf<double> LUv, Lv;
+                   DevBuf<int> s3_blob, s3_ptr, s3_topa, s3_topr; DevBuf<double> s3_schur, s3_xT; bool s3 = false; } plan_dev[2];
   DevBuf<int> sp_dflag;
+  DevBuf<double> sp_part;   // [S][8][SP_NP] per-workgroup partial reductions of the O(n) passes (ch_sparse.hpp)
+  DevBuf<double> sp_hpart, sp_hrow;   // slices of the heavy assembly items [S][items][SP_HB][2] and of the heavy rows of the charge update [S][rows][SP_RB]
   DevBuf<int> sp_rowptr, sp_colidx, sp_mat_gptr, sp_mat_gsrc, sp_vec_gptr, sp_vec_gsrc, sp_heavy_mat, sp_heavy_vec, sp_heavy_rows;
   int n_heavy_mat = 0, n_heavy_vec = 0, n_heavy_rows = 0;
   DevBuf<double> sp_stage, sp_Aval, sp_Cval, sp_F, sp_Q, sp_rhs, sp_y, sp_dx, sp_xcur, sp_xpred, sp_hq, sp_w, sp_qn;
@@ -783,6 +786,25 @@ struct ch_circuit {
     HIPCHK(pd.lrow_ptr.upload(P.lrow_ptr, st)); HIPCHK(pd.l_pos.upload(P.l_pos, st)); HIPCHK(pd.l_k.upload(P.l_k, st)); HIPCHK(pd.l_upd_ptr.upload(P.l_upd_ptr, st));
     HIPCHK(pd.upd_dst.upload(P.upd_dst, st)); HIPCHK(pd.upd_src.upload(P.upd_src, st)); HIPCHK(pd.urow_ptr.upload(P.urow_ptr, st)); HIPCHK(pd.u_pos.upload(P.u_pos, st)); HIPCHK(pd.u_col.upload(P.u_col, st));
     HIPCHK(pd.LUv.alloc((size_t)S * (size_t)P.nnz_lu));
+    // subtree form: many independent subtrees under a small separator (ch_sparse_host.hpp SubtreePlan) — three launches per solve
+    pd.s3 = P.sub.valid && std::getenv("CEDARHIP_SPARSE_NO_SUBTREE") == nullptr && std::getenv("CEDARHIP_SPARSE_ONE_WG") == nullptr;
+    if (pd.s3) {
+      const SubtreePlan& T = P.sub;
+      HIPCHK(pd.s3_blob.upload(T.blob, st)); HIPCHK(pd.s3_ptr.upload(T.blob_ptr, st));
+      { std::vector<int> ta = T.top_a_idx; if (ta.empty()) ta.push_back(-1); HIPCHK(pd.s3_topa.upload(ta, st)); }
+      { std::vector<int> tr = T.top_rows;   // [pivot index | rhs index | dx index] of every top row: one load level in the kernel
+        for (int k : T.top_rows) tr.push_back(P.prow[k]);
+        for (int k : T.top_rows) tr.push_back(P.pcol[k]);
+        if (tr.empty()) tr.push_back(0);
+        HIPCHK(pd.s3_topr.upload(tr, st)); }
+      HIPCHK(pd.s3_schur.alloc((size_t)S * (size_t)std::max(1, T.nT * T.nT + T.nT) * (size_t)T.n_groups));
+      HIPCHK(pd.s3_xT.alloc((size_t)S * (size_t)std::max(1, T.nT)));
+      const int lds3 = T.max_nv * 8 + T.max_blob * 4;
+      HIPCHK(hipFuncSetAttribute((const void*)sp3_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds3, 64 * 1024)));
+      HIPCHK(hipFuncSetAttribute((const void*)sp3_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds3, 64 * 1024)));
+      P.wide_levels = false;
+      return CH_OK;
+    }
     if (P.wide_levels && std::getenv("CEDARHIP_SPARSE_ONE_WG") == nullptr) {
       std::vector<int> lu2a((size_t)P.nnz_lu, -1);
       for (size_t i = 0; i < P.a2lu.size(); ++i) lu2a[P.a2lu[i]] = (int)i;
@@ -799,6 +821,18 @@ struct ch_circuit {
     hipStream_t st = ctx->stream;
     const SparsePlan& P = plan[which];
     const SparseDev d = sparse_dev(which);
+    if (plan_dev[which].s3) {
+      PlanDev& pd = plan_dev[which]; const SubtreePlan& T = P.sub;
+      Sp3Dev q; q.blob = pd.s3_blob.p; q.blob_ptr = pd.s3_ptr.p; q.top_a_idx = pd.s3_topa.p; q.top_rows = pd.s3_topr.p; q.schur = pd.s3_schur.p; q.xT = pd.s3_xT.p;
+      q.n_groups = T.n_groups; q.nT = T.nT; q.max_nv = T.max_nv;
+      const unsigned lds3 = (unsigned)(T.max_nv * 8 + T.max_blob * 4);
+      hipLaunchKernelGGL(sp3_reset_kernel, dim3(1, (unsigned)n_work), dim3(64), 0, st, d, wl);
+      hipLaunchKernelGGL(sp3_group_kernel, dim3((unsigned)T.n_groups, (unsigned)n_work), dim3(64), lds3, st, d, wl, q);
+      hipLaunchKernelGGL(sp3_top_kernel, dim3(1, (unsigned)n_work), dim3(256), 0, st, d, wl, q);
+      hipLaunchKernelGGL(sp3_back_kernel, dim3((unsigned)T.n_groups, (unsigned)n_work), dim3(64), lds3, st, d, wl, q);
+      n_launch += 4;
+      return;
+    }
     if (!P.wide_levels) { hipLaunchKernelGGL(sp_lu_solve_kernel, dim3(1, (unsigned)n_work), dim3(1024), 0, st, d, wl); return; }
     const unsigned ny = (unsigned)n_work;
     hipLaunchKernelGGL(sp2_scatter_kernel, dim3((unsigned)((P.nnz_lu + 255) / 256), ny), dim3(256), 0, st, d, wl);
@@ -890,6 +924,12 @@ struct ch_circuit {
     const dim3 b256(256), b1k(1024);
     auto grid = [&](int nx, size_t nl) { return dim3((unsigned)nx, (unsigned)nl); };
     const int gn = (n + 255) / 256, gd = (nd + 63) / 64, ga = (std::max(n, nnz) + 255) / 256;
+    // the O(n) passes: one workgroup per sample for small systems, up to SP_NP workgroups + a finishing pass from 4096 rows
+    const bool many = n >= 4096;
+    const int nbr = std::min(SP_NP, gn);
+    g_arena = &arena;
+    if (many) { HIPCHK(sp_part.alloc((size_t)S * 8 * SP_NP)); HIPCHK(sp_hrow.alloc((size_t)S * std::max(1, n_heavy_rows) * SP_RB)); }
+    if (n_heavy_mat + n_heavy_vec > 0) HIPCHK(sp_hpart.alloc((size_t)S * (n_heavy_mat + n_heavy_vec) * SP_HB * 2));
     // slot 0: every sample of this solve (predict, commit); slot 1: samples still iterating; slot 2: samples to (re)factor
     int rc = stage_list(0, todo); if (rc != CH_OK) return rc;
     hipLaunchKernelGGL(sp_predict_kernel, grid(gn, todo.size()), b256, 0, st, a, sparse_dev(which), (const int*)sp_act[0].p);
@@ -899,11 +939,17 @@ struct ch_circuit {
     for (int it = 0; it <= maxit && !act.empty(); ++it) {
       {
         const SparseDev d = sparse_dev(which); const int* al = sp_act[1].p;
-        hipLaunchKernelGGL(sp_eval_kernel, grid(gd, act.size()), dim3(64), 0, st, a, d, al);
+        hipLaunchKernelGGL(sp_eval_kernel, grid(A.wide ? gd : 2 * gd, act.size()), dim3(64), 0, st, a, d, al);
         hipLaunchKernelGGL(sp_assemble_kernel, grid(ga, act.size()), b256, 0, st, a, d, al);
-        if (n_heavy_mat + n_heavy_vec > 0) hipLaunchKernelGGL(sp_assemble_heavy_kernel, grid(n_heavy_mat + n_heavy_vec, act.size()), b256, 0, st, a, d, al);
+        if (n_heavy_mat + n_heavy_vec > 0) {
+          hipLaunchKernelGGL(sp_assemble_heavy_kernel, grid((n_heavy_mat + n_heavy_vec) * SP_HB, act.size()), b256, 0, st, a, d, al, sp_hpart.p);
+          hipLaunchKernelGGL(sp_assemble_heavy_finish_kernel, grid(n_heavy_mat + n_heavy_vec, act.size()), dim3(64), 0, st, a, d, al, (const double*)sp_hpart.p);
+        }
         if (a.gshunt != 0.0) hipLaunchKernelGGL(sp_diag_shunt_kernel, grid(gn, act.size()), b256, 0, st, a, d, al);
-        if (a.mode == MODE_DC) hipLaunchKernelGGL(sp_norms_kernel, grid(1, act.size()), b1k, 0, st, a, d, al, 0);
+        if (a.mode == MODE_DC) {
+          if (many) { hipLaunchKernelGGL(sp_norms2_kernel, grid(nbr, act.size()), b256, 0, st, a, d, al, 0, sp_part.p, nbr); hipLaunchKernelGGL(sp_finish_kernel, grid(1, act.size()), b256, 0, st, d, al, (const double*)sp_part.p, nbr, 2, (const double*)sp_hrow.p, 0); }
+          else hipLaunchKernelGGL(sp_norms_kernel, grid(1, act.size()), b1k, 0, st, a, d, al, 0);
+        }
         n_launch += 2;
       }
       if (a.mode == MODE_EVAL) { for (int sm : act) status[sm] = 0; break; }
@@ -929,7 +975,8 @@ struct ch_circuit {
         launch_lu_solve(which, wl, work.size());
         const double* sc = nullptr;
         if (damp) {
-          hipLaunchKernelGGL(sp_norms_kernel, grid(1, work.size()), b1k, 0, st, a, d, wl, 1);
+          if (many) { hipLaunchKernelGGL(sp_norms2_kernel, grid(nbr, work.size()), b256, 0, st, a, d, wl, 1, sp_part.p, nbr); hipLaunchKernelGGL(sp_finish_kernel, grid(1, work.size()), b256, 0, st, d, wl, (const double*)sp_part.p, nbr, 3, (const double*)sp_hrow.p, 0); }
+          else hipLaunchKernelGGL(sp_norms_kernel, grid(1, work.size()), b1k, 0, st, a, d, wl, 1);
           rc = sp_sync(); if (rc != CH_OK) return rc;
           for (int sm : work) { scale[sm] = 1.0; const double mx = h_red[(size_t)sm * 8 + 1]; if (!h_flag[(size_t)sm * 2] && mx > a.dv_max) scale[sm] = a.dv_max / mx; }
           g_arena = &arena;
@@ -938,7 +985,10 @@ struct ch_circuit {
           HIPCHK(hipMemcpyAsync(sp_scale.p, h_scale, (size_t)S * sizeof(double), hipMemcpyHostToDevice, st));
           sc = sp_scale.p;
         }
-        hipLaunchKernelGGL(sp_update_kernel, grid(1, work.size()), b1k, 0, st, a, d, wl, sc);  // no-op where the factorisation failed
+        if (many) {   // no-op where the factorisation failed
+          hipLaunchKernelGGL(sp_update2_kernel, grid(nbr + n_heavy_rows * SP_RB, work.size()), b256, 0, st, a, d, wl, sc, sp_part.p, nbr, sp_hrow.p);
+          hipLaunchKernelGGL(sp_finish_kernel, grid(1, work.size()), b256, 0, st, d, wl, (const double*)sp_part.p, nbr, 0, (const double*)sp_hrow.p, a.mode == MODE_TRAN ? 1 : 0);
+        } else hipLaunchKernelGGL(sp_update_kernel, grid(1, work.size()), b1k, 0, st, a, d, wl, sc);
         rc = sp_sync(); if (rc != CH_OK) return rc;
         n_launch += 2;
         std::vector<int> failed;
@@ -973,7 +1023,10 @@ struct ch_circuit {
       if (keep.size() != act.size()) { act.swap(keep); if (!act.empty()) { rc = stage_list(1, act); if (rc != CH_OK) return rc; } }
     }
     for (int sm : todo) if (a.mode == MODE_TRAN && status[sm] == 0) sp_rate_v[sm] = iters[sm] >= 2 ? std::min(1.0, std::max(rate_new[sm], 1e-4)) : std::min(1.0, rate_prev[sm] * 1.5);
-    hipLaunchKernelGGL(sp_commit_kernel, grid(1, todo.size()), b1k, 0, st, a, sparse_dev(which), (const int*)sp_act[0].p, (a.mode == MODE_TRAN) ? 0 : 1);
+    if (many) {
+      hipLaunchKernelGGL(sp_commit2_kernel, grid(nbr, todo.size()), b256, 0, st, a, sparse_dev(which), (const int*)sp_act[0].p, (a.mode == MODE_TRAN) ? 0 : 1, sp_part.p, nbr);
+      hipLaunchKernelGGL(sp_finish_kernel, grid(1, todo.size()), b256, 0, st, sparse_dev(which), (const int*)sp_act[0].p, (const double*)sp_part.p, nbr, 1, (const double*)sp_hrow.p, 0);
+    } else hipLaunchKernelGGL(sp_commit_kernel, grid(1, todo.size()), b1k, 0, st, a, sparse_dev(which), (const int*)sp_act[0].p, (a.mode == MODE_TRAN) ? 0 : 1);
     rc = sp_sync(); if (rc != CH_OK) return rc;
     n_launch += 1;
     for (int sm : todo) {

@@ -81,10 +81,31 @@ __global__ void sp_predict_kernel(const NewtonArgs a, const SparseDev d0, const 
   d.w[i] = 1.0 / (a.reltol * fabs(x0) + a.abstol);
 }
 
-// one thread per device instance: stamps to HBM
+// BSIM4 by function: PART 0 stores the current half of the record (I, dI/dV), PART 1 the charge half (Q, dQ/dV); the compiler drops
+// what a half does not store (3 925 and 3 395 instructions against 6 289 — the split of the device-resident stepper's wave pairs)
+template <int PART>
+__device__ __noinline__ void sp_mos_half(const B4Col P, double v0, double v1, double v2, double v3, double gmin, double m, double* st) {
+  double o[40];
+  b4_device(P, v0, v1, v2, v3, gmin, o);
+  if (PART != 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j] = m * o[j];
+#pragma unroll
+    for (int j = 8; j < 24; ++j) st[j] = m * o[j];
+  }
+  if (PART != 0) {
+#pragma unroll
+    for (int j = 4; j < 8; ++j) st[j] = m * o[j];
+#pragma unroll
+    for (int j = 24; j < 40; ++j) st[j] = m * o[j];
+  }
+}
+// one thread per device instance: stamps to HBM.  Narrow records (no compiled Verilog-A device): two workgroups per 64 devices, the even
+// one evaluates the current halves of the MOSFETs and every other device, the odd one the charge halves (grid.x = 2 * ceil(n_dev / 64)).
 __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
   const SparseDev d = sp_pick(d0, act);
-  const int dev = blockIdx.x * blockDim.x + threadIdx.x;
+  const int part = d.wide ? -1 : (int)(blockIdx.x & 1);
+  const int dev = (d.wide ? blockIdx.x : blockIdx.x >> 1) * blockDim.x + threadIdx.x;
   if (dev >= d.n_dev) return;
   const int sm = d.s;
   const double* kvl = a.inline_vals ? nullptr : a.kv + (long)(a.Ssrc > 1 ? sm : 0) * a.nk;
@@ -121,12 +142,12 @@ __global__ __launch_bounds__(64) void sp_eval_kernel(const NewtonArgs a, const S
   double* st = d.wide ? tmp40 : st_final;
   if (kind == K_MOS) {
     const B4Col P = b4_col(a.mosp, (long)a.dcls[dev] * a.Smos + (a.Smos > 1 ? sm : 0));
-    double o[40];
-    b4_device(P, v[0], v[1], v[2], v[3], gmin, o);
-    for (int j = 0; j < 40; ++j) st[j] = m * o[j];
-    if (d.wide) widen_stamp(st, st_final);
+    if (part == 0) sp_mos_half<0>(P, v[0], v[1], v[2], v[3], gmin, m, st);
+    else if (part == 1) sp_mos_half<1>(P, v[0], v[1], v[2], v[3], gmin, m, st);
+    else { sp_mos_half<-1>(P, v[0], v[1], v[2], v[3], gmin, m, st); widen_stamp(st, st_final); }
     return;
   }
+  if (part == 1) return;   // every other device belongs to the even workgroup
   for (int j = 0; j < 40; ++j) st[j] = 0.0;
   switch (kind) {
     case K_R: { const double g = m / a.dpar[pi], i = g * (v[0] - v[1]); st[0] = i; st[1] = -i; st[8] = g; st[9] = -g; st[12] = -g; st[13] = g; } break;
@@ -187,16 +208,20 @@ __device__ __forceinline__ void sp_block_sum2(double& x, double& y, double* sh) 
 }
 // the entries and rows with long gather lists (a supply rail shared by every tile collects one stamp per attached device): one
 // 256-thread workgroup per item, four sources in flight per thread, fixed-order reduction — deterministic like the light path
-__global__ __launch_bounds__(256) void sp_assemble_heavy_kernel(const NewtonArgs a, const SparseDev d0, const int* act) {
+// One workgroup cannot pull a rail's 2 - 4 MB of stamps through one CU's memory pipe in less than ~50 us (measured), so an item is
+// spread over SP_HB workgroups: each sums a contiguous slice (four sources in flight per thread, fixed order) into
+// hpart[sample][item][workgroup][2]; sp_assemble_heavy_finish_kernel adds the slices in order and writes the entry / row.
+constexpr int SP_HB = 64;
+__global__ __launch_bounds__(256) void sp_assemble_heavy_kernel(const NewtonArgs a, const SparseDev d0, const int* act, double* hpart) {
   const SparseDev d = sp_pick(d0, act);
   __shared__ double sh[8];
-  const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
-  const int item = blockIdx.x, t = threadIdx.x;
+  const int item = blockIdx.x / SP_HB, slice = blockIdx.x % SP_HB, t = threadIdx.x;
   const bool vec = item >= d.n_heavy_mat;
   const int e = vec ? d.heavy_vec[item - d.n_heavy_mat] : d.heavy_mat[item];
   const int* gp = vec ? d.vec_gptr : d.mat_gptr; const int* gs = vec ? d.vec_gsrc : d.mat_gsrc;
   const int off2 = vec ? d.q_ofs : d.c_ofs;
-  const int p0 = gp[e], p1 = gp[e + 1];
+  const int q0 = gp[e], q1 = gp[e + 1], per = (q1 - q0 + SP_HB - 1) / SP_HB;
+  const int p0 = q0 + slice * per, p1 = min(q1, p0 + per);
   double s1 = 0.0, s2 = 0.0;
   for (int p = p0 + t; p < p1; p += 4 * 256) {
     const int l = p1 - 1;
@@ -208,7 +233,18 @@ __global__ __launch_bounds__(256) void sp_assemble_heavy_kernel(const NewtonArgs
     if (p + 768 < p1) { s1 += a3; s2 += b3; }
   }
   sp_block_sum2(s1, s2, sh);
-  if (t == 0) {
+  if (t == 0) { double* hp = hpart + (((size_t)d.s * (d.n_heavy_mat + d.n_heavy_vec) + item) * SP_HB + slice) * 2; hp[0] = s1; hp[1] = s2; }
+}
+__global__ __launch_bounds__(64) void sp_assemble_heavy_finish_kernel(const NewtonArgs a, const SparseDev d0, const int* act, const double* hpart) {
+  const SparseDev d = sp_pick(d0, act);
+  const int item = blockIdx.x, lane = threadIdx.x;
+  const double alpha0 = a.mode == MODE_DC ? 0.0 : a.alpha[0];
+  const bool vec = item >= d.n_heavy_mat;
+  const int e = vec ? d.heavy_vec[item - d.n_heavy_mat] : d.heavy_mat[item];
+  const double* hp = hpart + (((size_t)d.s * (d.n_heavy_mat + d.n_heavy_vec) + item) * SP_HB) * 2;
+  double s1 = lane < SP_HB ? hp[lane * 2] : 0.0, s2 = lane < SP_HB ? hp[lane * 2 + 1] : 0.0;
+  s1 = sp_wave_sum(s1); s2 = sp_wave_sum(s2);
+  if (lane == 0) {
     if (vec) {
       if (a.gshunt != 0.0 && !(a.dmask[e] & 2)) s1 += a.gshunt * d.xcur[e];
       d.Q[e] = s2;
@@ -362,6 +398,155 @@ __global__ __launch_bounds__(256) void sp2_bwd_level_kernel(const SparseDev d0, 
   d.dx[d.pcol[k]] = s / d.LUv[d.diag_pos[k]];
 }
 
+// ---- subtree form (SubtreePlan, ch_sparse_host.hpp): independent subtrees in LDS, one wavefront each; a dense top block ---------------
+struct Sp3Dev {
+  const int* blob; const int* blob_ptr;     // per group
+  const int* top_a_idx; const int* top_rows;   // top_rows: [nT] pivot index | [nT] rhs index prow[.] | [nT] dx index pcol[.]
+  double* schur;                            // [S][nT*nT + nT][n_groups]: entry-major, so that the top kernel sums a contiguous run per entry
+  double* xT;                               // [S][nT]
+  int n_groups, nT, max_nv;
+};
+__global__ void sp3_reset_kernel(const SparseDev d0, const int* act) {   // the singular flags of this factorisation
+  const SparseDev d = sp_pick(d0, act);
+  if (threadIdx.x == 0) { d.flag[0] = 0; d.dflag[0] = 0; }
+}
+// one wavefront per group: load, up-looking elimination of the group's rows and of the top rows' segments, forward substitution,
+// Schur contributions.  grid (n_groups, samples), 64 threads, dynamic LDS = max_nv doubles + the largest blob.
+__global__ __launch_bounds__(64) void sp3_group_kernel(const SparseDev d0, const int* act, const Sp3Dev q) {
+  const SparseDev d = sp_pick(d0, act);
+  extern __shared__ double sp3_sh[];
+  double* val = sp3_sh;
+  int* B = (int*)(sp3_sh + q.max_nv);
+  const int g = blockIdx.x, lane = threadIdx.x;
+  {
+    const int4* src = (const int4*)(q.blob + q.blob_ptr[g]); int4* dst = (int4*)B;   // blobs are padded to 16 bytes
+    const int n4 = (q.blob_ptr[g + 1] - q.blob_ptr[g]) >> 2;
+    for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const Sp3Blob b(B);
+  for (int v0 = lane; v0 < b.nv; v0 += 64 * 4) {   // four loads in flight per lane
+    double x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int v = v0 + 64 * u; const int ai = v < b.nv ? b.a_idx[v] : -1; x[u] = ai >= 0 ? d.Aval[ai] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int v = v0 + 64 * u; if (v < b.nv) val[v] = x[u]; }
+  }
+  __syncthreads();   // (a y slot is a value slot: zeroed above, then set)
+  for (int f = lane; f < b.nrows; f += 64) val[b.fr_out[f]] = d.rhs[b.fr_rhs[f]];   // own rows: y starts as the right-hand side
+  __syncthreads();
+  bool sing = false;
+  for (int s = 0; s < b.ns; ++s) {
+    const int lp = b.st_lp[s];
+    const double pv = val[b.st_dp[s]];
+    if (!(fabs(pv) > 0.0) || !(fabs(pv) < 1e300)) sing = true;
+    const double l = val[lp] / pv;
+    for (int u = b.st_ub[s] + lane; u < b.st_ub[s + 1]; u += 64) { const int w = b.upd[u]; val[w >> 16] -= l * val[w & 0xffff]; }
+    if (lane == 0) val[lp] = l;   // (l_ik is neither a source nor a destination of its own step)
+    __syncthreads();
+  }
+  for (int f = 0; f < b.nfr; ++f) {
+    double acc = 0.0;
+    for (int e = b.fr_ptr[f] + lane; e < b.fr_ptr[f + 1]; e += 64) acc += val[b.fe_lp[e]] * val[b.fe_y[e]];
+    acc = sp2_wave_sum(acc);
+    if (lane == 0) val[b.fr_out[f]] -= acc;
+    __syncthreads();
+  }
+  for (int v = lane; v < b.n_own; v += 64) d.LUv[b.lu_pos[v]] = val[v];
+  for (int i = lane; i < b.nrows; i += 64) {
+    d.y[b.rowk[i]] = val[b.y0 + i];
+    const double pv = val[b.br_diag[b.nrows - 1 - i]];   // the pivots of the group's own rows (the last of them divides nothing above)
+    if (!(fabs(pv) > 0.0) || !(fabs(pv) < 1e300)) sing = true;
+  }
+  const int ne = q.nT * q.nT + q.nT;
+  double* so = q.schur + (size_t)d.s * ne * q.n_groups;
+  for (int j = lane; j < ne; j += 64) so[(size_t)j * q.n_groups + g] = j < q.nT * q.nT ? val[b.schur0 + j] : val[b.acc0 + (j - q.nT * q.nT)];
+  if (__any(sing)) { if (lane == 0) { d.flag[0] = 1; d.dflag[0] = 1; } }
+}
+// the top block: S = A_TT + sum over groups (fixed order), right-hand side likewise, dense LU with partial pivoting, x_T.
+// grid (1, samples), 256 threads.
+__global__ __launch_bounds__(256) void sp3_top_kernel(const SparseDev d0, const int* act, const Sp3Dev q) {
+  const SparseDev d = sp_pick(d0, act);
+  __shared__ double S[16 * 17];
+  __shared__ double base[16 * 17];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nT = q.nT, ne = nT * nT + nT;
+  const double* so = q.schur + (size_t)d.s * ne * q.n_groups;
+  // A's own entries and the right-hand sides: one thread each, all loads in flight together
+  for (int j = t; j < ne; j += 256) {
+    if (j < nT * nT) { const int ai = q.top_a_idx[j]; base[j] = ai >= 0 ? d.Aval[ai] : 0.0; }
+    else base[j] = d.rhs[q.top_rows[nT + (j - nT * nT)]];
+  }
+  __syncthreads();
+  // one wavefront per entry: the groups' contributions, lanes striding over the groups, fixed-order tree
+  for (int j = wave; j < ne; j += 4) {
+    double a = 0.0;
+    for (int g0 = lane; g0 < q.n_groups; g0 += 64 * 8) {   // eight loads in flight per lane (one at a time, each waited for its own
+      double v[8];                                          // memory round trip: 68 us for 1024 groups), summed in a fixed order
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int g = g0 + 64 * u; v[u] = g < q.n_groups ? so[(size_t)j * q.n_groups + g] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    a = sp2_wave_sum(a);
+    if (lane == 0) { if (j < nT * nT) S[(j / nT) * (nT + 1) + (j % nT)] = base[j] + a; else S[(j - nT * nT) * (nT + 1) + nT] = base[j] + a; }
+  }
+  __syncthreads();
+  if (t == 0 && nT > 0) {
+    bool sing = d.dflag[0] != 0;
+    const int ld = nT + 1;
+    for (int k = 0; k < nT && !sing; ++k) {
+      int bi = k; double best = fabs(S[k * ld + k]);
+      for (int i = k + 1; i < nT; ++i) if (fabs(S[i * ld + k]) > best) { best = fabs(S[i * ld + k]); bi = i; }
+      if (!(best > 0.0) || !(best < 1e300)) { sing = true; break; }
+      if (bi != k) for (int j = 0; j <= nT; ++j) { const double tmp = S[k * ld + j]; S[k * ld + j] = S[bi * ld + j]; S[bi * ld + j] = tmp; }
+      for (int i = k + 1; i < nT; ++i) { const double l = S[i * ld + k] / S[k * ld + k]; for (int j = k + 1; j <= nT; ++j) S[i * ld + j] -= l * S[k * ld + j]; }
+    }
+    if (sing) { d.flag[0] = 1; d.dflag[0] = 1; }
+    else for (int k = nT - 1; k >= 0; --k) {
+      double sx = S[k * ld + nT];
+      for (int j = k + 1; j < nT; ++j) sx -= S[k * ld + j] * S[j * ld + nT];
+      sx /= S[k * ld + k];
+      S[k * ld + nT] = sx;
+    }
+  }
+  __syncthreads();
+  if (t < nT && !d.dflag[0]) { const double x = S[t * (nT + 1) + nT]; q.xT[(size_t)d.s * nT + t] = x; d.dx[q.top_rows[2 * nT + t]] = x; }
+}
+// backward substitution of the groups with x_T.  grid (n_groups, samples), 64 threads.
+__global__ __launch_bounds__(64) void sp3_back_kernel(const SparseDev d0, const int* act, const Sp3Dev q) {
+  const SparseDev d = sp_pick(d0, act);
+  extern __shared__ double sp3_sh[];
+  double* val = sp3_sh;
+  int* B = (int*)(sp3_sh + q.max_nv);
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (d.dflag[0]) return;
+  {
+    const int4* src = (const int4*)(q.blob + q.blob_ptr[g]); int4* dst = (int4*)B;
+    const int n4 = (q.blob_ptr[g + 1] - q.blob_ptr[g]) >> 2;
+    for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const Sp3Blob b(B);
+  for (int v0 = lane; v0 < b.n_own; v0 += 64 * 4) {   // four loads in flight per lane
+    double x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int v = v0 + 64 * u; x[u] = v < b.n_own ? d.LUv[b.lu_pos[v]] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int v = v0 + 64 * u; if (v < b.n_own) val[v] = x[u]; }
+  }
+  for (int i = lane; i < b.nrows; i += 64) val[b.y0 + i] = d.y[b.rowk[i]];            // y, overwritten by x row by row
+  for (int t = lane; t < q.nT; t += 64) val[b.acc0 + t] = q.xT[(size_t)d.s * q.nT + t];
+  __syncthreads();
+  for (int r = 0; r < b.nbr; ++r) {
+    const int i = b.nrows - 1 - r;
+    double acc = 0.0;
+    for (int e = b.br_ptr[r] + lane; e < b.br_ptr[r + 1]; e += 64) { const int xr = b.be_x[e]; acc += val[b.be_up[e]] * (xr >= 0 ? val[b.y0 + xr] : val[b.acc0 + (-xr - 1)]); }
+    acc = sp2_wave_sum(acc);
+    if (lane == 0) { const double x = (val[b.y0 + i] - acc) / val[b.br_diag[r]]; val[b.y0 + i] = x; d.dx[b.br_col[r]] = x; }
+    __syncthreads();
+  }
+}
+
 // reductions: red[0]=max|F|, red[1]=max|dx| over node rows, red[2]=sum (dx*w)^2, red[3]=bad flag
 __global__ __launch_bounds__(1024) void sp_norms_kernel(const NewtonArgs a, const SparseDev d0, const int* act, int what) {
   const SparseDev d = sp_pick(d0, act);
@@ -414,6 +599,137 @@ __global__ __launch_bounds__(1024) void sp_update_kernel(const NewtonArgs a, con
   for (int i = t; i < d.n; i += 1024) d.xcur[i] += scale * d.dx[i];
   for (int o = 512; o > 0; o >>= 1) { if (t < o) s2[t] += s2[t + o]; __syncthreads(); }
   if (t == 0) { d.red[2] = s2[0]; d.flag[1] = sbad; }
+}
+
+// ---- the O(n) passes on many workgroups ----------------------------------------------------------------------------------------
+// sp_norms / sp_update / sp_commit above run ONE workgroup per sample — fine for a chain of a few hundred unknowns, 76 us for the
+// 11 266 rows of the coupled 1024-DFF array (one CU of 256).  Stage 1: up to SP_NP workgroups of 256 rows each, every workgroup
+// leaves its fixed-order partial sums in part[sample][k][workgroup]; stage 2 (sp_finish_kernel, one workgroup): the partials summed
+// in workgroup order — deterministic — into the mapped reduction record.  Rows with long C rows (rails) get a workgroup of their own.
+constexpr int SP_NP = 1024;
+__device__ __forceinline__ double sp_block_sum1(double x, double* sh) {   // 256 threads, fixed order
+  x = sp_wave_sum(x);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wv] = x;
+  __syncthreads();
+  return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+constexpr int SP_RB = 16;
+__global__ __launch_bounds__(256) void sp_update2_kernel(const NewtonArgs a, const SparseDev d0, const int* act, const double* scale_v, double* part, int nb_rows, double* hrow) {
+  const SparseDev d = sp_pick(d0, act);
+  __shared__ double sh[4];
+  double* pp = part + (size_t)d.s * 8 * SP_NP;
+  const int t = threadIdx.x, b = blockIdx.x;
+  const double scale = scale_v ? scale_v[d.s] : 1.0;
+  const bool dead = d.dflag[0] != 0;   // factorisation failed: leave the iterate untouched (the host re-analyses and retries)
+  if (b < nb_rows) {
+    double e2 = 0.0, bad = 0.0;
+    if (!dead) for (int i = b * 256 + t; i < d.n; i += nb_rows * 256) {
+      const double dxi = scale * d.dx[i];
+      const double xn = d.xcur[i] + dxi;
+      if (!(xn == xn) || fabs(xn) > 1e300) bad = 1.0;
+      const double tt = dxi * d.w[i]; e2 += tt * tt;
+      if (a.mode == MODE_TRAN && d.rowptr[i + 1] - d.rowptr[i] <= 256) { double q = d.Q[i]; for (int p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) q += d.Cval[p] * scale * d.dx[d.colidx[p]]; d.qn[i] = q; }
+      d.xcur[i] = xn;   // (the charge rows read dx, never xcur: no ordering between rows)
+    }
+    e2 = sp_block_sum1(e2, sh);
+    bad = sp_block_sum1(bad, sh);
+    if (t == 0) { pp[2 * SP_NP + b] = e2; pp[3 * SP_NP + b] = bad; }
+  } else if (a.mode == MODE_TRAN) {   // a long row (a rail): SP_RB workgroups, a contiguous slice each, four entries in flight per thread
+    const int h = (b - nb_rows) / SP_RB, slice = (b - nb_rows) % SP_RB;
+    const int i = d.heavy_rows[h];
+    const int q0 = d.rowptr[i], q1 = d.rowptr[i + 1], per = (q1 - q0 + SP_RB - 1) / SP_RB;
+    const int r0 = q0 + slice * per, r1 = min(q1, r0 + per);
+    double q = 0.0;
+    if (!dead) for (int p = r0 + t; p < r1; p += 4 * 256) {
+      const int l = r1 - 1;
+      const int p1 = min(p + 256, l), p2 = min(p + 512, l), p3 = min(p + 768, l);
+      const double c0 = d.Cval[p], c1 = d.Cval[p1], c2 = d.Cval[p2], c3 = d.Cval[p3];
+      const double x0 = d.dx[d.colidx[p]], x1 = d.dx[d.colidx[p1]], x2 = d.dx[d.colidx[p2]], x3 = d.dx[d.colidx[p3]];
+      q += c0 * scale * x0;
+      if (p + 256 < r1) q += c1 * scale * x1;
+      if (p + 512 < r1) q += c2 * scale * x2;
+      if (p + 768 < r1) q += c3 * scale * x3;
+    }
+    q = sp_block_sum1(q, sh);
+    if (t == 0) hrow[((size_t)d.s * d.n_heavy_rows + h) * SP_RB + slice] = q;
+  }
+}
+__global__ __launch_bounds__(256) void sp_commit2_kernel(const NewtonArgs a, const SparseDev d0, const int* act, int use_q_of_eval, double* part, int nb_rows) {
+  const SparseDev d = sp_pick(d0, act);
+  __shared__ double sh[4];
+  double* pp = part + (size_t)d.s * 8 * SP_NP;
+  const int t = threadIdx.x, b = blockIdx.x;
+  double e2k = 0, e2m = 0, e2p = 0, nd = 0;
+  for (int i = b * 256 + t; i < d.n; i += nb_rows * 256) {
+    const double xn = d.xcur[i];
+    a.X[(long)a.cand_slot * a.slot_stride + d.xofs + i] = xn;
+    a.Qh[(long)a.cand_slot * a.slot_stride + d.xofs + i] = use_q_of_eval ? d.Q[i] : d.qn[i];
+    if (a.obs_row) { const int ob = a.unk_obs[i]; if (ob >= 0) a.obs_row[(long)ob * a.S + d.s] = xn; }
+    if (a.mode == MODE_TRAN && (a.dmask[i] & 1)) {
+      const double x0 = a.X[(long)a.hist_slot[0] * a.slot_stride + d.xofs + i];
+      const double w = 1.0 / (a.reltol * fmax(fabs(x0), fabs(xn)) + a.abstol);
+      nd += 1.0;
+      double tt = (xn - d.xpred[i]) * w; e2k += tt * tt;
+      if (a.nkm1 > 0) { double p = 0.0; for (int j = 0; j < a.nkm1; ++j) p += a.wkm1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + d.xofs + i]; tt = (xn - p) * w; e2m += tt * tt; }
+      if (a.nkp1 > 0) { double p = 0.0; for (int j = 0; j < a.nkp1; ++j) p += a.wkp1[j + 1] * a.X[(long)a.hist_slot[j] * a.slot_stride + d.xofs + i]; tt = (xn - p) * w; e2p += tt * tt; }
+    }
+  }
+  e2k = sp_block_sum1(e2k, sh); e2m = sp_block_sum1(e2m, sh); e2p = sp_block_sum1(e2p, sh); nd = sp_block_sum1(nd, sh);
+  if (t == 0) { pp[4 * SP_NP + b] = e2k; pp[5 * SP_NP + b] = e2m; pp[6 * SP_NP + b] = e2p; pp[7 * SP_NP + b] = nd; }
+}
+// what: 0 max|F| -> part[0], 1 max|dx| over node rows -> part[1]
+__global__ __launch_bounds__(256) void sp_norms2_kernel(const NewtonArgs a, const SparseDev d0, const int* act, int what, double* part, int nb_rows) {
+  const SparseDev d = sp_pick(d0, act);
+  __shared__ double sh[4];
+  double* pp = part + (size_t)d.s * 8 * SP_NP;
+  const int t = threadIdx.x, b = blockIdx.x;
+  double m = 0.0;
+  for (int i = b * 256 + t; i < d.n; i += nb_rows * 256) {
+    if (what == 0) m = fmax(m, fabs(d.F[i]));
+    else if (!(a.dmask[i] & 2)) m = fmax(m, fabs(d.dx[i]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  __syncthreads();
+  if ((t & 63) == 0) sh[t >> 6] = m;
+  __syncthreads();
+  if (t == 0) pp[what * SP_NP + b] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+// stage 2: kind 0 = update (red[2] = sum, flag[1] = any bad), 1 = commit (red[4..7] = sums), 2 / 3 = norms (red[0] / red[1] = max)
+__global__ __launch_bounds__(256) void sp_finish_kernel(const SparseDev d0, const int* act, const double* part, int nb_rows, int kind, const double* hrow, int tran) {
+  const SparseDev d = sp_pick(d0, act);
+  __shared__ double sh[4];
+  const double* pp = part + (size_t)d.s * 8 * SP_NP;
+  const int t = threadIdx.x;
+  if (kind == 0 && tran && !d.dflag[0]) for (int h = t; h < d.n_heavy_rows; h += 256) {   // the long rows of the charge update: their slices in order
+    const double* hp = hrow + ((size_t)d.s * d.n_heavy_rows + h) * SP_RB;
+    double q = 0.0;
+    for (int k = 0; k < SP_RB; ++k) q += hp[k];
+    const int i = d.heavy_rows[h];
+    d.qn[i] = d.Q[i] + q;
+  }
+  if (kind >= 2) {
+    const int k = kind - 2;
+    double m = 0.0;
+    for (int b = t; b < nb_rows; b += 256) m = fmax(m, pp[k * SP_NP + b]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    __syncthreads();
+    if ((t & 63) == 0) sh[t >> 6] = m;
+    __syncthreads();
+    if (t == 0) d.red[k] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    return;
+  }
+  const int k0 = kind == 0 ? 2 : 4, k1 = kind == 0 ? 4 : 8;
+  for (int k = k0; k < k1; ++k) {
+    double s = 0.0;
+    for (int b = t; b < nb_rows; b += 256) s += pp[k * SP_NP + b];
+    s = sp_block_sum1(s, sh);
+    if (t == 0) { if (kind == 0 && k == 3) d.flag[1] = s > 0.0 ? 1 : 0; else d.red[k] = s; }
+    __syncthreads();
+  }
 }
 
 // commit candidate state, observables, local-error sums: red[4..7] = e2k, e2km1, e2kp1, ndiff

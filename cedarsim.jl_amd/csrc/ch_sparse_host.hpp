@@ -19,8 +19,52 @@
 namespace chip {
 
 
+// ---- subtree form ("sp3"): independent subtrees of the elimination tree under a small top separator --------------------------------
+// A tiled array behind shared rails factors as ~1000 identical 11-row subtrees hanging under a 2-row separator.  The
+// level-synchronous kernels pay one launch per level for that (13 levels x factor / forward / backward = 40 launches per Newton
+// iteration); the elimination tree says the subtrees never talk to each other below the separator.  Here:
+//   top set T   rows with a long L part, and everything that depends on them (closed under L and U): the separator;
+//   groups      connected components of the remaining rows (edges: every L and U entry between two of them): the subtrees;
+//   group g     ONE wavefront, its values staged in LDS: up-looking elimination of its own rows AND of the segments of the top rows
+//               that lie in its columns (the top rows' L entries whose pivots belong to g), forward substitution, and its
+//               contribution to the Schur complement on T — written to its own slot, so the sum over groups has a fixed order;
+//   top         one workgroup: S = A_TT + sum_g contributions, dense LU with partial pivoting, x_T;
+//   groups      backward substitution with x_T.
+// Three launches per refactorisation + solve.  Everything a group does is described by ONE int blob (copied to LDS first):
+// header | a_idx[nv] | lu_pos[nv] | steps {lp, dp, upd begin} | updates {dst << 16 | src} | forward rows and entries | backward
+// rows and entries.  Value slots (doubles in LDS): [entries of own rows | entries (r, k) of the top rows, k in g | Schur
+// accumulators nT x nT | y of own rows | forward accumulators of the top rows nT].
+struct SubtreePlan {
+  bool valid = false;
+  int n_groups = 0, nT = 0, max_blob = 0, max_nv = 0, max_rows = 0;
+  std::vector<int> top_rows;                 // pivot indices of T, ascending
+  std::vector<int> blob, blob_ptr;           // per group [blob_ptr[g], blob_ptr[g+1])
+  // top block: S[t][t'] starts from A's own entry (or 0), its right-hand side from rhs[prow[top_rows[t]]]
+  std::vector<int> top_a_idx;                // [nT * nT] index into A's values, or -1
+  enum { H_NV = 0, H_NOWN, H_NROWS, H_NSTEPS, H_NUPD, H_NFR, H_NFE, H_NBR, H_NBE, H_SCHUR, H_Y, H_ACC, H_WORDS = 16 };
+};
+
+#if defined(__HIPCC__)
+#define CH_SP_HD __host__ __device__
+#else
+#define CH_SP_HD
+#endif
+struct Sp3Blob {   // views into a group's blob (LDS)
+  int nv, n_own, nrows, ns, nu, nfr, nfe, nbr, nbe, schur0, y0, acc0;
+  const int *a_idx, *lu_pos, *st_lp, *st_dp, *st_ub, *upd, *fr_ptr, *fr_rhs, *fr_out, *fe_lp, *fe_y, *br_ptr, *br_diag, *br_col, *be_up, *be_x, *rowk;
+  CH_SP_HD explicit Sp3Blob(const int* B) {
+    nv = B[SubtreePlan::H_NV]; n_own = B[SubtreePlan::H_NOWN]; nrows = B[SubtreePlan::H_NROWS]; ns = B[SubtreePlan::H_NSTEPS]; nu = B[SubtreePlan::H_NUPD];
+    nfr = B[SubtreePlan::H_NFR]; nfe = B[SubtreePlan::H_NFE]; nbr = B[SubtreePlan::H_NBR]; nbe = B[SubtreePlan::H_NBE];
+    schur0 = B[SubtreePlan::H_SCHUR]; y0 = B[SubtreePlan::H_Y]; acc0 = B[SubtreePlan::H_ACC];
+    a_idx = B + SubtreePlan::H_WORDS; lu_pos = a_idx + nv; st_lp = lu_pos + nv; st_dp = st_lp + ns; st_ub = st_dp + ns; upd = st_ub + ns + 1;
+    fr_ptr = upd + nu; fr_rhs = fr_ptr + nfr + 1; fr_out = fr_rhs + nfr; fe_lp = fr_out + nfr; fe_y = fe_lp + nfe;
+    br_ptr = fe_y + nfe; br_diag = br_ptr + nbr + 1; br_col = br_diag + nbr; be_up = br_col + nbr; be_x = be_up + nbe; rowk = be_x + nbe;
+  }
+};
+
 struct SparsePlan {
   int n = 0;
+  SubtreePlan sub;
   // CSR pattern of A in unknown space + gather lists
   std::vector<int> rowptr, colidx;
   std::vector<int> mat_gptr, mat_gsrc;  // per nnz: staging offsets (G slot; C slot = +16)
@@ -250,6 +294,113 @@ inline int sparse_analyse(int n, const std::vector<int>& rowptr, const std::vect
     // worth a launch per level only when the levels are few and wide (a tiled array behind shared rails: 13 levels of ~1000
     // rows); a chain (RC ladder: one row per level) stays on the single-workgroup kernel
     P.wide_levels = nrl + nl + nul <= 144 && 3 * n >= 8 * (nrl + nl + nul);
+  }
+  // ---- subtree form ----
+  {
+    SubtreePlan& T = P.sub;
+    T = SubtreePlan();
+    std::vector<char> top(n, 0);
+    for (int k = 0; k < n; ++k) {
+      bool t = top[k] || (P.lrow_ptr[k + 1] - P.lrow_ptr[k] > SP_HEAVY);
+      for (int j : rowpat[k]) if (j < k && top[j]) t = true;
+      top[k] = t ? 1 : 0;
+      if (t) for (int j : rowpat[k]) if (j > k) top[j] = 1;   // the backward substitution of a top row needs x_j first
+    }
+    for (int k = 0; k < n; ++k) if (top[k]) T.top_rows.push_back(k);
+    T.nT = (int)T.top_rows.size();
+    std::vector<int> tix(n, -1);
+    for (int t = 0; t < T.nT; ++t) tix[T.top_rows[t]] = t;
+    // groups: union-find over the non-top rows
+    std::vector<int> par(n);
+    std::iota(par.begin(), par.end(), 0);
+    auto find = [&](int x) { while (par[x] != x) { par[x] = par[par[x]]; x = par[x]; } return x; };
+    for (int k = 0; k < n; ++k) if (!top[k]) for (int j : rowpat[k]) if (j != k && !top[j]) { const int a = find(k), b = find(j); if (a != b) par[std::max(a, b)] = std::min(a, b); }
+    std::vector<int> gid(n, -1);
+    std::vector<std::vector<int>> rows_of;
+    for (int k = 0; k < n; ++k) if (!top[k]) { const int r = find(k); if (gid[r] < 0) { gid[r] = (int)rows_of.size(); rows_of.emplace_back(); } gid[k] = gid[r]; rows_of[gid[k]].push_back(k); }
+    T.n_groups = (int)rows_of.size();
+    bool ok = T.nT <= 16 && T.n_groups >= 64;
+    // the top rows' L entries by group
+    std::vector<std::vector<std::pair<int, int>>> seg(ok ? T.n_groups : 0);   // per group: (top index, L-entry index e)
+    if (ok) for (int t = 0; t < T.nT; ++t) { const int r = T.top_rows[t]; for (int e = P.lrow_ptr[r]; e < P.lrow_ptr[r + 1]; ++e) { const int k = P.l_k[e]; if (!top[k]) seg[gid[k]].push_back({t, e}); } }
+    T.blob_ptr.assign(1, 0);
+    for (int g = 0; g < T.n_groups && ok; ++g) {
+      const std::vector<int>& R = rows_of[g];
+      std::map<int, int> slot;   // global LU position -> local slot
+      std::vector<int> a_idx, lu_pos;
+      auto add_slot = [&](int gpos) { auto it = slot.find(gpos); if (it != slot.end()) return it->second; const int v = (int)lu_pos.size(); slot[gpos] = v; lu_pos.push_back(gpos); a_idx.push_back(-1); return v; };
+      for (int k : R) for (int c : rowpat[k]) add_slot(find_pos(k, c));
+      const int n_own = (int)lu_pos.size();
+      for (auto& se : seg[g]) add_slot(P.l_pos[se.second]);
+      const int n_ent = (int)lu_pos.size();
+      const int schur0 = n_ent, y0 = schur0 + T.nT * T.nT, acc0 = y0 + (int)R.size(), nv = acc0 + T.nT;
+      for (int v = n_ent; v < nv; ++v) { lu_pos.push_back(-1); a_idx.push_back(-1); }
+      std::map<int, int> yslot; for (size_t i = 0; i < R.size(); ++i) yslot[R[i]] = y0 + (int)i;
+      // destination of an update of top row t in column c: an own-segment entry (c in the group) or a Schur accumulator (c in T)
+      std::vector<int> st_lp, st_dp, st_ub(1, 0), upd;
+      auto push_step = [&](int row, int e, int t_of_row) {
+        const int k = P.l_k[e];
+        st_lp.push_back(slot.at(P.l_pos[e])); st_dp.push_back(slot.at(P.diag_pos[k]));
+        for (int q = P.l_upd_ptr[e]; q < P.l_upd_ptr[e + 1]; ++q) {
+          int dst;
+          auto it = slot.find(P.upd_dst[q]);
+          if (it != slot.end()) dst = it->second;
+          else {   // (top row, top column): accumulate the contribution
+            if (t_of_row < 0) { ok = false; return; }
+            // which column? upd_dst is find_pos(row, c): recover c from the source position (same column in pivot row k)
+            const auto& rp = rowpat[k]; const int c = rp[P.upd_src[q] - lu_ptr[k]];
+            if (tix[c] < 0) { ok = false; return; }
+            dst = schur0 + t_of_row * T.nT + tix[c];
+          }
+          upd.push_back((dst << 16) | slot.at(P.upd_src[q]));
+        }
+        st_ub.push_back((int)upd.size());
+      };
+      for (int k : R) for (int e = P.lrow_ptr[k]; e < P.lrow_ptr[k + 1] && ok; ++e) push_step(k, e, -1);
+      for (auto& se : seg[g]) { if (!ok) break; push_step(T.top_rows[se.first], se.second, se.first); }
+      if (!ok || nv >= 32768) { ok = false; break; }
+      // original values of A
+      for (int k : R) { const int r = P.prow[k]; for (int pp = rowptr[r]; pp < rowptr[r + 1]; ++pp) a_idx[slot.at(P.a2lu[pp])] = pp; }
+      for (int t = 0; t < T.nT; ++t) { const int r = P.prow[T.top_rows[t]]; for (int pp = rowptr[r]; pp < rowptr[r + 1]; ++pp) { auto it = slot.find(P.a2lu[pp]); if (it != slot.end() && it->second >= n_own) a_idx[it->second] = pp; } }
+      // forward rows: own rows (y = rhs - sum l y), then the top rows' partial sums (acc = - sum l y over this group's pivots)
+      std::vector<int> fr_ptr(1, 0), fr_rhs, fr_out, fe_lp, fe_y;
+      for (int k : R) { for (int e = P.lrow_ptr[k]; e < P.lrow_ptr[k + 1]; ++e) { fe_lp.push_back(slot.at(P.l_pos[e])); fe_y.push_back(yslot.at(P.l_k[e])); } fr_ptr.push_back((int)fe_lp.size()); fr_rhs.push_back(P.prow[k]); fr_out.push_back(yslot.at(k)); }
+      for (int t = 0; t < T.nT; ++t) {
+        int cnt = 0;
+        for (auto& se : seg[g]) if (se.first == t) { fe_lp.push_back(slot.at(P.l_pos[se.second])); fe_y.push_back(yslot.at(P.l_k[se.second])); ++cnt; }
+        fr_ptr.push_back((int)fe_lp.size()); fr_rhs.push_back(-1); fr_out.push_back(acc0 + t);
+      }
+      // backward rows, descending: x_k = (y_k - sum u_kj x_j) / u_kk ; x_j local (>= 0: index into R) or top (-(t+1))
+      std::vector<int> br_ptr(1, 0), br_diag, br_col, be_up, be_x;
+      std::map<int, int> rix; for (size_t i = 0; i < R.size(); ++i) rix[R[i]] = (int)i;
+      for (int i = (int)R.size() - 1; i >= 0; --i) {
+        const int k = R[i];
+        for (int e = P.urow_ptr[k]; e < P.urow_ptr[k + 1]; ++e) { const int j = P.u_col[e]; be_up.push_back(slot.at(P.u_pos[e])); be_x.push_back(top[j] ? -(tix[j] + 1) : rix.at(j)); }
+        br_ptr.push_back((int)be_up.size()); br_diag.push_back(slot.at(P.diag_pos[k])); br_col.push_back(P.pcol[k]);
+      }
+      // blob
+      std::vector<int> b(SubtreePlan::H_WORDS, 0);
+      b[SubtreePlan::H_NV] = nv; b[SubtreePlan::H_NOWN] = n_own; b[SubtreePlan::H_NROWS] = (int)R.size(); b[SubtreePlan::H_NSTEPS] = (int)st_lp.size(); b[SubtreePlan::H_NUPD] = (int)upd.size();
+      b[SubtreePlan::H_NFR] = (int)fr_rhs.size(); b[SubtreePlan::H_NFE] = (int)fe_lp.size(); b[SubtreePlan::H_NBR] = (int)br_diag.size(); b[SubtreePlan::H_NBE] = (int)be_up.size();
+      b[SubtreePlan::H_SCHUR] = schur0; b[SubtreePlan::H_Y] = y0; b[SubtreePlan::H_ACC] = acc0;
+      auto app = [&](const std::vector<int>& v) { b.insert(b.end(), v.begin(), v.end()); };
+      app(a_idx); app(lu_pos); app(st_lp); app(st_dp); app(st_ub); app(upd);
+      app(fr_ptr); app(fr_rhs); app(fr_out); app(fe_lp); app(fe_y);
+      app(br_ptr); app(br_diag); app(br_col); app(be_up); app(be_x);
+      std::vector<int> rowk(R.begin(), R.end()); app(rowk);   // pivot index of every own row (the global y of the row)
+      while (b.size() & 3) b.push_back(0);
+      T.max_blob = std::max(T.max_blob, (int)b.size()); T.max_nv = std::max(T.max_nv, nv); T.max_rows = std::max(T.max_rows, (int)R.size());
+      T.blob.insert(T.blob.end(), b.begin(), b.end());
+      T.blob_ptr.push_back((int)T.blob.size());
+    }
+    if (ok) {
+      T.top_a_idx.assign((size_t)T.nT * T.nT, -1);
+      for (int t = 0; t < T.nT; ++t) { const int r = P.prow[T.top_rows[t]]; for (int pp = rowptr[r]; pp < rowptr[r + 1]; ++pp) { const int c = pos_of_col[colidx[pp]]; if (tix[c] >= 0) T.top_a_idx[(size_t)t * T.nT + tix[c]] = pp; } }
+      // LDS of a group's wavefront: the blob + the values; a workgroup is one wavefront
+      ok = (size_t)T.max_blob * 4 + (size_t)T.max_nv * 8 <= 60 * 1024;
+    }
+    T.valid = ok;
+    if (!ok) { T.blob.clear(); T.blob_ptr.clear(); }
   }
   P.valid = true;
   return CH_OK;

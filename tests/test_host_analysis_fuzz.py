@@ -30,6 +30,20 @@ def test_sparse_analysis_is_sanitizer_clean_on_random_matrices(tmp_path):
     assert "fail 0" in r.stdout
 
 
+def test_subtree_form_of_the_sparse_analysis_replays_exactly(tmp_path):
+    """SubtreePlan (ch_sparse_host.hpp): arrow matrices — 64 to 100 independent blocks under a border of one to three rows — are split
+    into groups + a top block, and a host replay of what sp3_group_kernel / sp3_top_kernel / sp3_back_kernel do with the blobs equals a
+    dense solve with partial pivoting; under ASan / UBSan / _GLIBCXX_ASSERTIONS."""
+    exe = str(tmp_path / "st_fuzz")
+    r = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-D_GLIBCXX_ASSERTIONS",
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cedarsim.jl_amd", "csrc"),
+                        os.path.join(ROOT, "tests", "host_subtree_fuzz.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "60 plans replayed" in r.stdout and " 0 failures" in r.stdout
+
+
 def test_return_address_scanner_flags_the_pattern(tmp_path):
     """scripts/check_return_address.py on two hand-written device functions: one whose long-branch expansion writes s[30:31]
     without a saved copy (the code-generator defect worked around in csrc/va_rt.hpp), one that saved the pair first."""
