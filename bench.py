@@ -89,7 +89,25 @@ def cpu_baseline(seconds_single=5.0, seconds_multi=10.0, seconds_proxy=5.0):
     t0 = time.perf_counter()
     itp, repsp = _oracle_worker((t0 + seconds_proxy, 200, True))
     elp = time.perf_counter() - t0
-    proxy = {"kind": "proxy, not CedarSim", "value": itp / elp / N_TILES, "unit": "newton_iters/s (1024-DFF array equivalent)", "cores": 1,
+    # the term the per-tile proxy leaves out: IDA's dense LU is of the WHOLE system (`solve(prob, IDA())` uses Sundials' dense
+    # default).  One LAPACK dgetrf of a random 4096 x 4096 matrix is timed on this host (a few seconds) and scaled by (13 312 / 4096)^3
+    # to the size of the array's system — an extrapolation, labelled as one; the full size is 1.6 TFLOP per refactorisation
+    dense_lu = None
+    try:
+        import numpy as _np
+        import scipy.linalg as _sl
+        n_meas, n_full = 4096, 13 * N_TILES
+        _m = _np.random.default_rng(0).standard_normal((n_meas, n_meas))
+        _t0 = time.perf_counter()
+        _sl.lu_factor(_m, overwrite_a=True, check_finite=False)
+        _el = time.perf_counter() - _t0
+        dense_lu = {"n_measured": n_meas, "seconds_measured": _el, "n_full": n_full, "seconds_full_extrapolated_cubic": _el * (n_full / n_meas) ** 3,
+                    "what": "scipy.linalg.lu_factor (LAPACK dgetrf as this numpy/scipy build runs it on the host's cores): what ONE Jacobian refresh of "
+                            "IDA's dense default adds per refactorisation of the whole array; not included in `value`"}
+        del _m
+    except Exception as ex:  # noqa: BLE001
+        dense_lu = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    proxy = {"kind": "proxy, not CedarSim", "value": itp / elp / N_TILES, "dense_lu_of_the_whole_system": dense_lu, "unit": "newton_iters/s (1024-DFF array equivalent)", "cores": 1,
              "seconds_per_tile_transient": elp / repsp, "seconds_per_array_transient_scaled": elp / repsp * N_TILES,
              "sample": "%d full transients of one decoupled tile with a finite-difference Jacobian (26 residuals each) reused across "
                        "iterations and steps, %.1f s" % (repsp, elp)}
