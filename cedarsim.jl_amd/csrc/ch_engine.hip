@@ -555,7 +555,12 @@ struct ch_circuit {
       std::vector<double> key;
       key.push_back(d.ipar[0]);
       for (int k = 0; k < 7; ++k) key.push_back(std::isnan(d.par[k]) ? -1e300 : d.par[k]);
-      for (int i = 0; i < nslot; ++i) if (slot_set(i) && slot_kind[i] == CH_SLOT_DEV_PAR && slot_a[i] == A.mos_hdev[m]) key.push_back(1e6 + i);
+      // an overriding slot: which field, and its values in every sample — instances whose overrides are EQUAL (a global W / L delta
+      // of a Monte-Carlo sweep gives every device its own slot, but devices of one geometry the same values) still share a column
+      for (int i = 0; i < nslot; ++i) if (slot_set(i) && slot_kind[i] == CH_SLOT_DEV_PAR && slot_a[i] == A.mos_hdev[m]) {
+        key.push_back(1e6 + slot_b[i]);
+        key.insert(key.end(), slot_val[i].begin(), slot_val[i].end());
+      }
       auto it = cls_of.find(key);
       if (it == cls_of.end()) { it = cls_of.insert({key, (int)cls_rep.size()}).first; cls_rep.push_back(m); }
       mos_cls[m] = it->second;

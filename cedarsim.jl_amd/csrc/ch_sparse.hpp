@@ -410,8 +410,9 @@ __global__ void sp3_reset_kernel(const SparseDev d0, const int* act) {   // the 
   const SparseDev d = sp_pick(d0, act);
   if (threadIdx.x == 0) { d.flag[0] = 0; d.dflag[0] = 0; }
 }
-// one wavefront per group: load, up-looking elimination of the group's rows and of the top rows' segments, forward substitution,
-// Schur contributions.  grid (n_groups, samples), 64 threads, dynamic LDS = max_nv doubles + the largest blob.
+// one wavefront per group: load; ONE step per pivot — every lane takes fused updates a_ic -= (a_ik / u_kk) u_kc and
+// y_i -= (a_ik / u_kk) y_k (nothing a step reads is written by it: one barrier per pivot); Schur contributions.
+// grid (n_groups, samples), 64 threads, dynamic LDS = max_nv doubles + the largest blob.
 __global__ __launch_bounds__(64) void sp3_group_kernel(const SparseDev d0, const int* act, const Sp3Dev q) {
   const SparseDev d = sp_pick(d0, act);
   extern __shared__ double sp3_sh[];
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(64) void sp3_group_kernel(const SparseDev d0, const
     for (int i = lane; i < n4; i += 64) dst[i] = src[i];
   }
   __syncthreads();
-  const Sp3Blob b(B);
+  const Sp3Blob b(B, q.nT);
   for (int v0 = lane; v0 < b.nv; v0 += 64 * 4) {   // four loads in flight per lane
     double x[4];
 #pragma unroll
@@ -433,35 +434,25 @@ __global__ __launch_bounds__(64) void sp3_group_kernel(const SparseDev d0, const
     for (int u = 0; u < 4; ++u) { const int v = v0 + 64 * u; if (v < b.nv) val[v] = x[u]; }
   }
   __syncthreads();   // (a y slot is a value slot: zeroed above, then set)
-  for (int f = lane; f < b.nrows; f += 64) val[b.fr_out[f]] = d.rhs[b.fr_rhs[f]];   // own rows: y starts as the right-hand side
+  for (int i = lane; i < b.np; i += 64) val[b.y0 + i] = d.rhs[b.rhs_idx[i]];   // own rows: y starts as the right-hand side
   __syncthreads();
   bool sing = false;
-  for (int s = 0; s < b.ns; ++s) {
-    const int lp = b.st_lp[s];
-    const double pv = val[b.st_dp[s]];
+  for (int pi = 0; pi < b.np; ++pi) {
+    const double pv = val[b.piv_dp[pi]];
     if (!(fabs(pv) > 0.0) || !(fabs(pv) < 1e300)) sing = true;
-    const double l = val[lp] / pv;
-    for (int u = b.st_ub[s] + lane; u < b.st_ub[s + 1]; u += 64) { const int w = b.upd[u]; val[w >> 16] -= l * val[w & 0xffff]; }
-    if (lane == 0) val[lp] = l;   // (l_ik is neither a source nor a destination of its own step)
-    __syncthreads();
-  }
-  for (int f = 0; f < b.nfr; ++f) {
-    double acc = 0.0;
-    for (int e = b.fr_ptr[f] + lane; e < b.fr_ptr[f + 1]; e += 64) acc += val[b.fe_lp[e]] * val[b.fe_y[e]];
-    acc = sp2_wave_sum(acc);
-    if (lane == 0) val[b.fr_out[f]] -= acc;
+    for (int u = b.fu_ptr[pi] + lane; u < b.fu_ptr[pi + 1]; u += 64) {
+      const int w = b.fu_ds[u];
+      const double l = val[b.fu_lp[u]] / pv;
+      val[w >> 16] -= l * val[w & 0xffff];
+    }
     __syncthreads();
   }
   for (int v = lane; v < b.n_own; v += 64) d.LUv[b.lu_pos[v]] = val[v];
-  for (int i = lane; i < b.nrows; i += 64) {
-    d.y[b.rowk[i]] = val[b.y0 + i];
-    const double pv = val[b.br_diag[b.nrows - 1 - i]];   // the pivots of the group's own rows (the last of them divides nothing above)
-    if (!(fabs(pv) > 0.0) || !(fabs(pv) < 1e300)) sing = true;
-  }
+  for (int i = lane; i < b.np; i += 64) d.y[b.rowk[i]] = val[b.y0 + i];
   const int ne = q.nT * q.nT + q.nT;
   double* so = q.schur + (size_t)d.s * ne * q.n_groups;
   for (int j = lane; j < ne; j += 64) so[(size_t)j * q.n_groups + g] = j < q.nT * q.nT ? val[b.schur0 + j] : val[b.acc0 + (j - q.nT * q.nT)];
-  if (__any(sing)) { if (lane == 0) { d.flag[0] = 1; d.dflag[0] = 1; } }
+  if (sing && lane == 0) { d.flag[0] = 1; d.dflag[0] = 1; }
 }
 // the top block: S = A_TT + sum over groups (fixed order), right-hand side likewise, dense LU with partial pivoting, x_T.
 // grid (1, samples), 256 threads.
@@ -512,7 +503,8 @@ __global__ __launch_bounds__(256) void sp3_top_kernel(const SparseDev d0, const 
   __syncthreads();
   if (t < nT && !d.dflag[0]) { const double x = S[t * (nT + 1) + nT]; q.xT[(size_t)d.s * nT + t] = x; d.dx[q.top_rows[2 * nT + t]] = x; }
 }
-// backward substitution of the groups with x_T.  grid (n_groups, samples), 64 threads.
+// backward substitution of the groups with x_T, column-oriented: first y_i -= u_iT x_T for every top unknown, then the pivots in
+// descending order: x_k = y_k / u_kk, y_i -= u_ik x_k for the rows of the group that hold column k.  grid (n_groups, samples), 64 threads.
 __global__ __launch_bounds__(64) void sp3_back_kernel(const SparseDev d0, const int* act, const Sp3Dev q) {
   const SparseDev d = sp_pick(d0, act);
   extern __shared__ double sp3_sh[];
@@ -526,7 +518,7 @@ __global__ __launch_bounds__(64) void sp3_back_kernel(const SparseDev d0, const 
     for (int i = lane; i < n4; i += 64) dst[i] = src[i];
   }
   __syncthreads();
-  const Sp3Blob b(B);
+  const Sp3Blob b(B, q.nT);
   for (int v0 = lane; v0 < b.n_own; v0 += 64 * 4) {   // four loads in flight per lane
     double x[4];
 #pragma unroll
@@ -534,16 +526,20 @@ __global__ __launch_bounds__(64) void sp3_back_kernel(const SparseDev d0, const 
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int v = v0 + 64 * u; if (v < b.n_own) val[v] = x[u]; }
   }
-  for (int i = lane; i < b.nrows; i += 64) val[b.y0 + i] = d.y[b.rowk[i]];            // y, overwritten by x row by row
+  for (int i = lane; i < b.np; i += 64) val[b.y0 + i] = d.y[b.rowk[i]];            // y, overwritten by x pivot by pivot
   for (int t = lane; t < q.nT; t += 64) val[b.acc0 + t] = q.xT[(size_t)d.s * q.nT + t];
   __syncthreads();
-  for (int r = 0; r < b.nbr; ++r) {
-    const int i = b.nrows - 1 - r;
-    double acc = 0.0;
-    for (int e = b.br_ptr[r] + lane; e < b.br_ptr[r + 1]; e += 64) { const int xr = b.be_x[e]; acc += val[b.be_up[e]] * (xr >= 0 ? val[b.y0 + xr] : val[b.acc0 + (-xr - 1)]); }
-    acc = sp2_wave_sum(acc);
-    if (lane == 0) { const double x = (val[b.y0 + i] - acc) / val[b.br_diag[r]]; val[b.y0 + i] = x; d.dx[b.br_col[r]] = x; }
+  for (int t = 0; t < q.nT; ++t) {   // (a row holds a top column at most once: the targets of one t are distinct)
+    const double xt = val[b.acc0 + t];
+    for (int e = b.bt_ptr[t] + lane; e < b.bt_ptr[t + 1]; e += 64) val[b.bt_y[e]] -= val[b.bt_up[e]] * xt;
     __syncthreads();
+  }
+  for (int r = 0; r < b.np; ++r) {
+    const int pi = b.np - 1 - r;
+    const double x = val[b.y0 + pi] / val[b.piv_dp[pi]];
+    for (int e = b.bc_ptr[r] + lane; e < b.bc_ptr[r + 1]; e += 64) val[b.bc_y[e]] -= val[b.bc_up[e]] * x;   // rows above the pivot: never y_pi itself
+    __syncthreads();
+    if (lane == 0) { val[b.y0 + pi] = x; d.dx[b.dx_idx[pi]] = x; }
   }
 }
 

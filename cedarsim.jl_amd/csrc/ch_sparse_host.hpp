@@ -30,10 +30,15 @@ namespace chip {
 //               contribution to the Schur complement on T — written to its own slot, so the sum over groups has a fixed order;
 //   top         one workgroup: S = A_TT + sum_g contributions, dense LU with partial pivoting, x_T;
 //   groups      backward substitution with x_T.
-// Three launches per refactorisation + solve.  Everything a group does is described by ONE int blob (copied to LDS first):
-// header | a_idx[nv] | lu_pos[nv] | steps {lp, dp, upd begin} | updates {dst << 16 | src} | forward rows and entries | backward
-// rows and entries.  Value slots (doubles in LDS): [entries of own rows | entries (r, k) of the top rows, k in g | Schur
-// accumulators nT x nT | y of own rows | forward accumulators of the top rows nT].
+// Three launches per refactorisation + solve.  Everything a group does is described by ONE int blob (copied to LDS first).  The
+// elimination inside a group is COLUMN-oriented (right-looking): one step per pivot, in which every lane takes one update
+// a_ic -= (a_ik / u_kk) u_kc — or the matching step of the forward substitution, y_i -= (a_ik / u_kk) y_k, which rides along (y_k is
+// final when pivot k is reached) — and nothing a step reads is written by it, so a step is one barrier; the multipliers are never
+// stored (the backward substitution needs U and the pivots only).  Eleven steps for an 11-row tile instead of 77 L entries.
+// blob: header | a_idx[nv] | lu_pos[nv] | piv_dp[np] | fu_ptr[np+1] | fu_ds[] = dst << 16 | src | fu_lp[] | rhs_idx[np] | rowk[np]
+//       | bt_ptr[nT+1] | bt_up[] | bt_y[] | bc_ptr[np+1] (pivots descending) | bc_up[] | bc_y[] | dx_idx[np]
+// Value slots (doubles in LDS): [entries of own rows | entries (r, k) of the top rows, k in g | Schur accumulators nT x nT | y of
+// own rows | forward accumulators of the top rows nT].
 struct SubtreePlan {
   bool valid = false;
   int n_groups = 0, nT = 0, max_blob = 0, max_nv = 0, max_rows = 0;
@@ -41,7 +46,7 @@ struct SubtreePlan {
   std::vector<int> blob, blob_ptr;           // per group [blob_ptr[g], blob_ptr[g+1])
   // top block: S[t][t'] starts from A's own entry (or 0), its right-hand side from rhs[prow[top_rows[t]]]
   std::vector<int> top_a_idx;                // [nT * nT] index into A's values, or -1
-  enum { H_NV = 0, H_NOWN, H_NROWS, H_NSTEPS, H_NUPD, H_NFR, H_NFE, H_NBR, H_NBE, H_SCHUR, H_Y, H_ACC, H_WORDS = 16 };
+  enum { H_NV = 0, H_NOWN, H_NROWS, H_NFU, H_NBT, H_NBC, H_SCHUR, H_Y, H_ACC, H_WORDS = 12 };
 };
 
 #if defined(__HIPCC__)
@@ -50,15 +55,14 @@ struct SubtreePlan {
 #define CH_SP_HD
 #endif
 struct Sp3Blob {   // views into a group's blob (LDS)
-  int nv, n_own, nrows, ns, nu, nfr, nfe, nbr, nbe, schur0, y0, acc0;
-  const int *a_idx, *lu_pos, *st_lp, *st_dp, *st_ub, *upd, *fr_ptr, *fr_rhs, *fr_out, *fe_lp, *fe_y, *br_ptr, *br_diag, *br_col, *be_up, *be_x, *rowk;
-  CH_SP_HD explicit Sp3Blob(const int* B) {
-    nv = B[SubtreePlan::H_NV]; n_own = B[SubtreePlan::H_NOWN]; nrows = B[SubtreePlan::H_NROWS]; ns = B[SubtreePlan::H_NSTEPS]; nu = B[SubtreePlan::H_NUPD];
-    nfr = B[SubtreePlan::H_NFR]; nfe = B[SubtreePlan::H_NFE]; nbr = B[SubtreePlan::H_NBR]; nbe = B[SubtreePlan::H_NBE];
+  int nv, n_own, np, nfu, nbt, nbc, schur0, y0, acc0;
+  const int *a_idx, *lu_pos, *piv_dp, *fu_ptr, *fu_ds, *fu_lp, *rhs_idx, *rowk, *bt_ptr, *bt_up, *bt_y, *bc_ptr, *bc_up, *bc_y, *dx_idx;
+  CH_SP_HD Sp3Blob(const int* B, int nT) {
+    nv = B[SubtreePlan::H_NV]; n_own = B[SubtreePlan::H_NOWN]; np = B[SubtreePlan::H_NROWS]; nfu = B[SubtreePlan::H_NFU]; nbt = B[SubtreePlan::H_NBT]; nbc = B[SubtreePlan::H_NBC];
     schur0 = B[SubtreePlan::H_SCHUR]; y0 = B[SubtreePlan::H_Y]; acc0 = B[SubtreePlan::H_ACC];
-    a_idx = B + SubtreePlan::H_WORDS; lu_pos = a_idx + nv; st_lp = lu_pos + nv; st_dp = st_lp + ns; st_ub = st_dp + ns; upd = st_ub + ns + 1;
-    fr_ptr = upd + nu; fr_rhs = fr_ptr + nfr + 1; fr_out = fr_rhs + nfr; fe_lp = fr_out + nfr; fe_y = fe_lp + nfe;
-    br_ptr = fe_y + nfe; br_diag = br_ptr + nbr + 1; br_col = br_diag + nbr; be_up = br_col + nbr; be_x = be_up + nbe; rowk = be_x + nbe;
+    a_idx = B + SubtreePlan::H_WORDS; lu_pos = a_idx + nv; piv_dp = lu_pos + nv; fu_ptr = piv_dp + np; fu_ds = fu_ptr + np + 1; fu_lp = fu_ds + nfu;
+    rhs_idx = fu_lp + nfu; rowk = rhs_idx + np; bt_ptr = rowk + np; bt_up = bt_ptr + nT + 1; bt_y = bt_up + nbt;
+    bc_ptr = bt_y + nbt; bc_up = bc_ptr + np + 1; bc_y = bc_up + nbc; dx_idx = bc_y + nbc;
   }
 };
 
@@ -336,58 +340,58 @@ inline int sparse_analyse(int n, const std::vector<int>& rowptr, const std::vect
       const int schur0 = n_ent, y0 = schur0 + T.nT * T.nT, acc0 = y0 + (int)R.size(), nv = acc0 + T.nT;
       for (int v = n_ent; v < nv; ++v) { lu_pos.push_back(-1); a_idx.push_back(-1); }
       std::map<int, int> yslot; for (size_t i = 0; i < R.size(); ++i) yslot[R[i]] = y0 + (int)i;
-      // destination of an update of top row t in column c: an own-segment entry (c in the group) or a Schur accumulator (c in T)
-      std::vector<int> st_lp, st_dp, st_ub(1, 0), upd;
-      auto push_step = [&](int row, int e, int t_of_row) {
-        const int k = P.l_k[e];
-        st_lp.push_back(slot.at(P.l_pos[e])); st_dp.push_back(slot.at(P.diag_pos[k]));
+      // fused updates, bucketed by pivot (the group's own rows in ascending order): for every L entry (i, k) — i an own row or a top
+      // row — its matrix updates {dst (i, c), src (k, c)} and the forward step {dst y_i or the top row's accumulator, src y_k}
+      std::map<int, int> pix; for (size_t i = 0; i < R.size(); ++i) pix[R[i]] = (int)i;
+      std::vector<std::vector<std::array<int, 3>>> fu(R.size());   // per pivot: {dst, src, lp}
+      auto push_entry = [&](int e, int t_of_row, int ydst) {
+        const int k = P.l_k[e], lp = slot.at(P.l_pos[e]), pi = pix.at(k);
         for (int q = P.l_upd_ptr[e]; q < P.l_upd_ptr[e + 1]; ++q) {
           int dst;
           auto it = slot.find(P.upd_dst[q]);
           if (it != slot.end()) dst = it->second;
           else {   // (top row, top column): accumulate the contribution
             if (t_of_row < 0) { ok = false; return; }
-            // which column? upd_dst is find_pos(row, c): recover c from the source position (same column in pivot row k)
-            const auto& rp = rowpat[k]; const int c = rp[P.upd_src[q] - lu_ptr[k]];
+            const auto& rp = rowpat[k]; const int c = rp[P.upd_src[q] - lu_ptr[k]];   // the column: same as the source's in pivot row k
             if (tix[c] < 0) { ok = false; return; }
             dst = schur0 + t_of_row * T.nT + tix[c];
           }
-          upd.push_back((dst << 16) | slot.at(P.upd_src[q]));
+          fu[pi].push_back({dst, slot.at(P.upd_src[q]), lp});
         }
-        st_ub.push_back((int)upd.size());
+        fu[pi].push_back({ydst, yslot.at(k), lp});
       };
-      for (int k : R) for (int e = P.lrow_ptr[k]; e < P.lrow_ptr[k + 1] && ok; ++e) push_step(k, e, -1);
-      for (auto& se : seg[g]) { if (!ok) break; push_step(T.top_rows[se.first], se.second, se.first); }
+      for (int k : R) for (int e = P.lrow_ptr[k]; e < P.lrow_ptr[k + 1] && ok; ++e) push_entry(e, -1, yslot.at(k));
+      for (auto& se : seg[g]) { if (!ok) break; push_entry(se.second, se.first, acc0 + se.first); }
       if (!ok || nv >= 32768) { ok = false; break; }
       // original values of A
       for (int k : R) { const int r = P.prow[k]; for (int pp = rowptr[r]; pp < rowptr[r + 1]; ++pp) a_idx[slot.at(P.a2lu[pp])] = pp; }
       for (int t = 0; t < T.nT; ++t) { const int r = P.prow[T.top_rows[t]]; for (int pp = rowptr[r]; pp < rowptr[r + 1]; ++pp) { auto it = slot.find(P.a2lu[pp]); if (it != slot.end() && it->second >= n_own) a_idx[it->second] = pp; } }
-      // forward rows: own rows (y = rhs - sum l y), then the top rows' partial sums (acc = - sum l y over this group's pivots)
-      std::vector<int> fr_ptr(1, 0), fr_rhs, fr_out, fe_lp, fe_y;
-      for (int k : R) { for (int e = P.lrow_ptr[k]; e < P.lrow_ptr[k + 1]; ++e) { fe_lp.push_back(slot.at(P.l_pos[e])); fe_y.push_back(yslot.at(P.l_k[e])); } fr_ptr.push_back((int)fe_lp.size()); fr_rhs.push_back(P.prow[k]); fr_out.push_back(yslot.at(k)); }
-      for (int t = 0; t < T.nT; ++t) {
-        int cnt = 0;
-        for (auto& se : seg[g]) if (se.first == t) { fe_lp.push_back(slot.at(P.l_pos[se.second])); fe_y.push_back(yslot.at(P.l_k[se.second])); ++cnt; }
-        fr_ptr.push_back((int)fe_lp.size()); fr_rhs.push_back(-1); fr_out.push_back(acc0 + t);
+      std::vector<int> piv_dp, fu_ptr(1, 0), fu_ds, fu_lp, rhs_idx, rowk, dx_idx;
+      for (size_t i = 0; i < R.size(); ++i) {
+        piv_dp.push_back(slot.at(P.diag_pos[R[i]]));
+        for (auto& u : fu[i]) { fu_ds.push_back((u[0] << 16) | u[1]); fu_lp.push_back(u[2]); }
+        fu_ptr.push_back((int)fu_ds.size());
+        rhs_idx.push_back(P.prow[R[i]]); rowk.push_back(R[i]); dx_idx.push_back(P.pcol[R[i]]);
       }
-      // backward rows, descending: x_k = (y_k - sum u_kj x_j) / u_kk ; x_j local (>= 0: index into R) or top (-(t+1))
-      std::vector<int> br_ptr(1, 0), br_diag, br_col, be_up, be_x;
-      std::map<int, int> rix; for (size_t i = 0; i < R.size(); ++i) rix[R[i]] = (int)i;
-      for (int i = (int)R.size() - 1; i >= 0; --i) {
-        const int k = R[i];
-        for (int e = P.urow_ptr[k]; e < P.urow_ptr[k + 1]; ++e) { const int j = P.u_col[e]; be_up.push_back(slot.at(P.u_pos[e])); be_x.push_back(top[j] ? -(tix[j] + 1) : rix.at(j)); }
-        br_ptr.push_back((int)be_up.size()); br_diag.push_back(slot.at(P.diag_pos[k])); br_col.push_back(P.pcol[k]);
+      // backward, column-oriented: first the top unknowns (y_i -= u_iT x_T), then the pivots in descending order
+      // (x_k = y_k / u_kk ; y_i -= u_ik x_k for the rows i < k of the group that hold column k)
+      std::vector<std::vector<std::pair<int, int>>> bt(T.nT), bc(R.size());   // (u slot, y slot of row i)
+      for (int k : R) for (int e = P.urow_ptr[k]; e < P.urow_ptr[k + 1]; ++e) {
+        const int j = P.u_col[e];
+        if (top[j]) bt[tix[j]].push_back({slot.at(P.u_pos[e]), yslot.at(k)});
+        else bc[pix.at(j)].push_back({slot.at(P.u_pos[e]), yslot.at(k)});
       }
+      std::vector<int> bt_ptr(1, 0), bt_up, bt_y, bc_ptr(1, 0), bc_up, bc_y;
+      for (int t = 0; t < T.nT; ++t) { for (auto& x : bt[t]) { bt_up.push_back(x.first); bt_y.push_back(x.second); } bt_ptr.push_back((int)bt_up.size()); }
+      for (int i = (int)R.size() - 1; i >= 0; --i) { for (auto& x : bc[i]) { bc_up.push_back(x.first); bc_y.push_back(x.second); } bc_ptr.push_back((int)bc_up.size()); }
       // blob
       std::vector<int> b(SubtreePlan::H_WORDS, 0);
-      b[SubtreePlan::H_NV] = nv; b[SubtreePlan::H_NOWN] = n_own; b[SubtreePlan::H_NROWS] = (int)R.size(); b[SubtreePlan::H_NSTEPS] = (int)st_lp.size(); b[SubtreePlan::H_NUPD] = (int)upd.size();
-      b[SubtreePlan::H_NFR] = (int)fr_rhs.size(); b[SubtreePlan::H_NFE] = (int)fe_lp.size(); b[SubtreePlan::H_NBR] = (int)br_diag.size(); b[SubtreePlan::H_NBE] = (int)be_up.size();
+      b[SubtreePlan::H_NV] = nv; b[SubtreePlan::H_NOWN] = n_own; b[SubtreePlan::H_NROWS] = (int)R.size(); b[SubtreePlan::H_NFU] = (int)fu_ds.size();
+      b[SubtreePlan::H_NBT] = (int)bt_up.size(); b[SubtreePlan::H_NBC] = (int)bc_up.size();
       b[SubtreePlan::H_SCHUR] = schur0; b[SubtreePlan::H_Y] = y0; b[SubtreePlan::H_ACC] = acc0;
       auto app = [&](const std::vector<int>& v) { b.insert(b.end(), v.begin(), v.end()); };
-      app(a_idx); app(lu_pos); app(st_lp); app(st_dp); app(st_ub); app(upd);
-      app(fr_ptr); app(fr_rhs); app(fr_out); app(fe_lp); app(fe_y);
-      app(br_ptr); app(br_diag); app(br_col); app(be_up); app(be_x);
-      std::vector<int> rowk(R.begin(), R.end()); app(rowk);   // pivot index of every own row (the global y of the row)
+      app(a_idx); app(lu_pos); app(piv_dp); app(fu_ptr); app(fu_ds); app(fu_lp); app(rhs_idx); app(rowk);
+      app(bt_ptr); app(bt_up); app(bt_y); app(bc_ptr); app(bc_up); app(bc_y); app(dx_idx);
       while (b.size() & 3) b.push_back(0);
       T.max_blob = std::max(T.max_blob, (int)b.size()); T.max_nv = std::max(T.max_nv, nv); T.max_rows = std::max(T.max_rows, (int)R.size());
       T.blob.insert(T.blob.end(), b.begin(), b.end());

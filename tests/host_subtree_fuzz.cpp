@@ -68,21 +68,27 @@ int main() {
     bool sing = false;
     for (int g = 0; g < T.n_groups; ++g) {   // sp3_group_kernel
       const int* B = T.blob.data() + T.blob_ptr[g];
-      const Sp3Blob b(B);
+      const Sp3Blob b(B, nT);
       if (b.nv > T.max_nv || T.blob_ptr[g + 1] - T.blob_ptr[g] > T.max_blob) { printf("blob larger than the recorded maximum\n"); ++nfail; }
+      if (b.dx_idx + b.np > T.blob.data() + T.blob_ptr[g + 1]) { printf("blob views run past the blob\n"); ++nfail; }
       std::vector<double> val(b.nv, 0.0);
       for (int v = 0; v < b.nv; ++v) { const int ai = b.a_idx[v]; val[v] = ai >= 0 ? av.at(ai) : 0.0; }
-      for (int f = 0; f < b.nrows; ++f) val.at(b.fr_out[f]) = rhs.at(b.fr_rhs[f]);
-      for (int s = 0; s < b.ns; ++s) {
-        const double pv = val.at(b.st_dp[s]);
+      for (int i = 0; i < b.np; ++i) val.at(b.y0 + i) = rhs.at(b.rhs_idx[i]);
+      for (int pi = 0; pi < b.np; ++pi) {
+        const double pv = val.at(b.piv_dp[pi]);
         if (!(std::fabs(pv) > 0.0)) sing = true;
-        const double l = val.at(b.st_lp[s]) / pv;
-        for (int u = b.st_ub[s]; u < b.st_ub[s + 1]; ++u) { const int w = b.upd[u]; val.at(w >> 16) -= l * val.at(w & 0xffff); }
-        val.at(b.st_lp[s]) = l;
+        std::vector<char> written(b.nv, 0), read(b.nv, 0);   // a step must not write what it reads (one barrier per pivot on the GPU)
+        for (int u = b.fu_ptr[pi]; u < b.fu_ptr[pi + 1]; ++u) { const int w = b.fu_ds[u]; read.at(b.fu_lp[u]) = 1; read.at(w & 0xffff) = 1; read.at(b.piv_dp[pi]) = 1; }
+        for (int u = b.fu_ptr[pi]; u < b.fu_ptr[pi + 1]; ++u) {
+          const int w = b.fu_ds[u];
+          if (read.at(w >> 16) || written.at(w >> 16)) { printf("pivot step %d of group %d writes a slot it reads or writes twice\n", pi, g); ++nfail; }
+          written.at(w >> 16) = 1;
+          const double l = val.at(b.fu_lp[u]) / pv;
+          val.at(w >> 16) -= l * val.at(w & 0xffff);
+        }
       }
-      for (int f = 0; f < b.nfr; ++f) { double acc = 0.0; for (int e = b.fr_ptr[f]; e < b.fr_ptr[f + 1]; ++e) acc += val.at(b.fe_lp[e]) * val.at(b.fe_y[e]); val.at(b.fr_out[f]) -= acc; }
       for (int v = 0; v < b.n_own; ++v) LUv.at(b.lu_pos[v]) = val[v];
-      for (int i = 0; i < b.nrows; ++i) y.at(b.rowk[i]) = val.at(b.y0 + i);
+      for (int i = 0; i < b.np; ++i) y.at(b.rowk[i]) = val.at(b.y0 + i);
       for (int j = 0; j < ne; ++j) schur[(size_t)j * T.n_groups + g] = j < nT * nT ? val.at(b.schur0 + j) : val.at(b.acc0 + (j - nT * nT));
     }
     {   // sp3_top_kernel
@@ -96,17 +102,20 @@ int main() {
       for (int t = 0; t < nT; ++t) dx.at(P.pcol[T.top_rows[t]]) = xT[t];
     }
     for (int g = 0; g < T.n_groups && !sing; ++g) {   // sp3_back_kernel
-      const Sp3Blob b(T.blob.data() + T.blob_ptr[g]);
+      const Sp3Blob b(T.blob.data() + T.blob_ptr[g], nT);
       std::vector<double> val(b.nv, 0.0);
       for (int v = 0; v < b.n_own; ++v) val[v] = LUv.at(b.lu_pos[v]);
-      for (int i = 0; i < b.nrows; ++i) val.at(b.y0 + i) = y.at(b.rowk[i]);
+      for (int i = 0; i < b.np; ++i) val.at(b.y0 + i) = y.at(b.rowk[i]);
       for (int t = 0; t < nT; ++t) val.at(b.acc0 + t) = xT[t];
-      for (int r = 0; r < b.nbr; ++r) {
-        const int i = b.nrows - 1 - r;
-        double acc = 0.0;
-        for (int e = b.br_ptr[r]; e < b.br_ptr[r + 1]; ++e) { const int xr = b.be_x[e]; acc += val.at(b.be_up[e]) * (xr >= 0 ? val.at(b.y0 + xr) : val.at(b.acc0 + (-xr - 1))); }
-        const double x = (val.at(b.y0 + i) - acc) / val.at(b.br_diag[r]);
-        val.at(b.y0 + i) = x; dx.at(b.br_col[r]) = x;
+      for (int t = 0; t < nT; ++t) {
+        std::vector<char> hit(b.nv, 0);
+        for (int e = b.bt_ptr[t]; e < b.bt_ptr[t + 1]; ++e) { if (hit.at(b.bt_y[e])) { printf("two entries of one top column in one row\n"); ++nfail; } hit.at(b.bt_y[e]) = 1; val.at(b.bt_y[e]) -= val.at(b.bt_up[e]) * val.at(b.acc0 + t); }
+      }
+      for (int r = 0; r < b.np; ++r) {
+        const int pi = b.np - 1 - r;
+        const double x = val.at(b.y0 + pi) / val.at(b.piv_dp[pi]);
+        for (int e = b.bc_ptr[r]; e < b.bc_ptr[r + 1]; ++e) { if (b.bc_y[e] == b.y0 + pi) { printf("a pivot's own y among its column targets\n"); ++nfail; } val.at(b.bc_y[e]) -= val.at(b.bc_up[e]) * x; }
+        val.at(b.y0 + pi) = x; dx.at(b.dx_idx[pi]) = x;
       }
     }
     std::vector<double> xr;
