@@ -188,11 +188,27 @@ def config4_sharded_sweep(ctx, rank, world, dist, backend, samples_per_rank=1024
         dist.barrier()
     if dev == "cuda":
         torch.cuda.synchronize()
+    # The gather.  With RCCL the rows go GPU to GPU straight from the engine's result buffer in HBM (ch_result_device_values through
+    # `__cuda_array_interface__`: no host round trip); the gathered tensor is copied to the host once afterwards, for the checks below,
+    # and that copy is timed apart.  Anything else (the gloo rehearsal, rows the engine did not keep on the device): host rows.
+    how, d2h_s = "host rows -> device staging -> all_gather -> host", None
     t0 = time.perf_counter()
-    full = gather_sharded(rows, S_total, rank, world, device=dev) if dist is not None else rows
-    if dev == "cuda":
+    drows = None if plumbing_only else stats.get("device_rows")
+    if dist is not None and dev == "cuda" and drows is not None:
+        from cedarsim_jl_amd import gather_sharded_device
+        local_dev = torch.as_tensor(drows, device="cuda")                    # zero-copy view of the engine's buffer [n_obs, n_save, samples]
+        full_dev = gather_sharded_device(local_dev, S_total, rank, world)    # [n_obs, n_save, S_total] on every rank
         torch.cuda.synchronize()
-    gather_s = time.perf_counter() - t0
+        gather_s = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        full = np.ascontiguousarray(full_dev.permute(2, 0, 1).cpu().numpy())
+        d2h_s = time.perf_counter() - t1
+        how = "engine's result buffer in HBM -> all_gather (RCCL, GPU to GPU); device -> host copy of the gathered rows timed apart"
+    else:
+        full = gather_sharded(rows, S_total, rank, world, device=dev) if dist is not None else rows
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        gather_s = time.perf_counter() - t0
     # every rank holds every sample's rows now: check the reference's gate on ALL of them, and that the shards landed in order
     ci = np.searchsorted(saveat, np.array(DFF_CHECK_TIMES))
     if plumbing_only:
@@ -221,7 +237,7 @@ def config4_sharded_sweep(ctx, rank, world, dist, backend, samples_per_rank=1024
             "gather": {"collective": "one all_gather of [samples/rank, n_obs, n_save] fp64 rows (%s)" % ("RCCL over xGMI" if backend == "nccl" else backend),
                        "bytes_per_rank": bytes_per_rank, "seconds_max_over_ranks": float(res[:, 1].max()),
                        "GBps_per_rank_received": (world - 1) * bytes_per_rank / max(1e-12, float(res[:, 1].max())) / 1e9 if world > 1 else None,
-                       "includes": "host -> device staging of the rank's rows, the collective, device -> host of the gathered rows"},
+                       "path": how, "device_to_host_seconds_rank0": d2h_s},
             "every_rank_sees_its_shard_in_place": bool(res[:, 4].min() > 0.5), "samples_passing_reference_gate": n_pass,
             "stepper": "device-resident, per-sample step acceptance" if stats.get("stepper") == 2 else ("plumbing only" if plumbing_only else "host"),
             "plumbing_only": bool(plumbing_only)}

@@ -592,6 +592,7 @@ class CircuitSweep:
             eng.set_params(slot_ids, vals)
         opts = tran_opts(abstol=abstol, reltol=reltol, saveat=saveat, dc=dc_opts(abstol=dc_abstol), **kw)
         rc, t, v, xf, st = eng.tran(tspan[0], tspan[1], opts)
+        self._last_engine = eng   # st["device_rows"] (the same rows still in HBM, [n_obs][n_times][samples]) lives as long as this circuit
         return rc, t, np.ascontiguousarray(np.transpose(v, (2, 0, 1))), st
 
     @staticmethod
@@ -605,6 +606,25 @@ class CircuitSweep:
             if sl[0] == SLOT_DEV_PAR:
                 c.dev_par[sl[1]][sl[2]] = float(vals[i][s])
         return c
+
+
+def gather_sharded_device(rows, n_total, rank, world, group=None):
+    """The same gather with the rows never leaving HBM: `rows` is a CUDA tensor [n_obs, n_times, n_local] (samples fastest — the
+    engine's own layout, e.g. `torch.as_tensor(stats["device_rows"], device="cuda")`); one `all_gather` over RCCL; returns a CUDA
+    tensor [n_obs, n_times, n_total] on every rank."""
+    import torch
+    import torch.distributed as dist
+    max_local = -(-n_total // world)
+    n_obs, n_t, n_loc = rows.shape
+    buf = rows if n_loc == max_local else torch.cat((rows, rows.new_zeros((n_obs, n_t, max_local - n_loc))), dim=2)
+    buf = buf.contiguous()
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        parts.append(out[r][:, :, :hi - lo])
+    return torch.cat(parts, dim=2)
 
 
 def gather_sharded(local, n_total, rank, world, group=None, device=None):

@@ -219,6 +219,7 @@ constexpr int NSLOT = 8;  // 7 history points + 1 candidate
 struct ch_result {
   std::vector<double> times, values, final_state;
   std::vector<int32_t> pts;   // per saved row: newest saved points (this row included) the step's dense-output polynomial runs through; 0 = none
+  const double* dev_values = nullptr; int64_t dev_n = 0;   // the same values still in HBM ([n_obs][n_times][n_samples]), owned by the circuit, or null
   ch_stats stats;
   int status = CH_OK;
   int n_obs = 0, S = 1;
@@ -1495,6 +1496,15 @@ struct ch_circuit {
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(R.values.data(), d_ptrans.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        // the rows stay in HBM for a device-side consumer (the RCCL gather of a sharded sweep) when every observable is a plain
+        // unknown — the host-side fix-ups of finish_tran (merged nodes, known nodes, eliminated branches) do not reach this buffer
+        bool plain = true;
+        for (int ob = 0; ob < n_obs && plain; ++ob) {
+          if (obs_primary[ob] != ob) plain = false;
+          else if (obs_kind[ob] == 0 && A.node_unknown[obs_index[ob]] < 0) plain = false;
+          else if (obs_kind[ob] == 1) { const int br = dev[obs_index[ob]].branch; if (br < 0 || A.branch_unknown[br] < 0) plain = false; }
+        }
+        if (plain) { R.dev_values = d_ptrans.p; R.dev_n = (int64_t)n; }
       }
     } else
     for (size_t r = 0; r < nt; ++r) for (int ob = 0; ob < n_obs; ++ob) std::memcpy(&R.values[((size_t)ob * nt + r) * S], &hrows[(r * n_obs + ob) * S], S * sizeof(double));
@@ -2086,6 +2096,11 @@ static int ch_tran_impl(ch_circuit* c, double t0, double t1, const ch_tran_opts*
 int64_t ch_result_n_times(const ch_result* r) { return r ? (int64_t)r->times.size() : 0; }
 const double* ch_result_times(const ch_result* r) { return r ? r->times.data() : nullptr; }
 const int32_t* ch_result_dense_points(const ch_result* r) { return (r && r->pts.size() == r->times.size()) ? r->pts.data() : nullptr; }
+int ch_result_device_values(const ch_result* r, const double** ptr, int64_t* n_doubles) {
+  if (!r || !ptr || !n_doubles) return CH_ERR_INVALID;
+  *ptr = r->dev_values; *n_doubles = r->dev_n;
+  return r->dev_values ? CH_OK : CH_ERR_UNSUPPORTED;
+}
 const double* ch_result_values(const ch_result* r) { return r ? r->values.data() : nullptr; }
 const double* ch_result_final_state(const ch_result* r) { return r ? r->final_state.data() : nullptr; }
 int ch_result_stats(const ch_result* r, ch_stats* s) { if (!r || !s) return CH_ERR_INVALID; *s = r->stats; return CH_OK; }

@@ -19,7 +19,7 @@ _pi32 = C.POINTER(C.c_int32)
 EXPORTS = [
     "ch_dc_opts_default", "ch_tran_opts_default", "ch_create", "ch_destroy", "ch_last_error", "ch_circuit_build",
     "ch_circuit_free", "ch_circuit_info", "ch_circuit_maps", "ch_set_samples", "ch_set_params", "ch_dc", "ch_tran",
-    "ch_result_n_times", "ch_result_times", "ch_result_dense_points", "ch_result_values", "ch_result_final_state", "ch_result_stats",
+    "ch_result_n_times", "ch_result_times", "ch_result_dense_points", "ch_result_device_values", "ch_result_values", "ch_result_final_state", "ch_result_stats",
     "ch_result_status", "ch_result_free", "ch_eval", "ch_ac", "ch_noise", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
     "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64", "ch_va_n_modules", "ch_va_find", "ch_va_module_name", "ch_va_module_info",
     "ch_va_node_name", "ch_va_param_name", "ch_va_eval", "ch_va_n_opvars", "ch_va_opvar_name", "ch_va_opvars", "ch_debug_poison_lds",
@@ -59,6 +59,7 @@ def load_library():
         getattr(L, f).argtypes = [vp]
     L.ch_result_dense_points.restype = _pi32
     L.ch_result_dense_points.argtypes = [vp]
+    L.ch_result_device_values.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.ch_result_stats.argtypes = [vp, C.POINTER(ChStats)]
     L.ch_result_status.argtypes = [vp]
     L.ch_result_free.argtypes = [vp]
@@ -178,6 +179,15 @@ def default_context(device_id=None):
     return _default_ctx[device_id]
 
 
+class DeviceRows:
+    """Result rows of the last transient still in HBM, [n_obs][n_times][n_samples] fp64, exposed through `__cuda_array_interface__`
+    (zero-copy: `torch.as_tensor(rows, device="cuda")`).  Owned by the engine circuit: valid until its next call; `owner` keeps it alive."""
+
+    def __init__(self, ptr, shape, owner):
+        self.ptr, self.shape, self.owner = int(ptr), tuple(int(x) for x in shape), owner
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 2, "strides": None}
+
+
 class EngineCircuit:
     """A circuit resident on the GPU: structure analysed once, parameters per sample."""
 
@@ -273,6 +283,10 @@ class EngineCircuit:
             dp = self.L.ch_result_dense_points(r)
             # per saved row: how many newest rows the step's dense-output polynomial runs through (0: none; api.Solution.__call__)
             sd["dense_points"] = np.ctypeslib.as_array(dp, (nt,)).copy() if (dp and nt) else None
+            # the same rows still in HBM (ch_result_device_values): a view for torch.as_tensor(..., device="cuda"), valid until the next call on this circuit
+            dptr, dn = C.c_void_p(), C.c_int64(0)
+            ok = self.L.ch_result_device_values(r, C.byref(dptr), C.byref(dn)) == 0 and dptr.value and dn.value == nobs * nt * S
+            sd["device_rows"] = DeviceRows(dptr.value, (nobs, nt, S), self) if ok else None
             return rc, t, v, xf, sd
         finally:
             self.L.ch_result_free(r)

@@ -267,6 +267,12 @@ const double* ch_result_values(const ch_result*); /* [n_obs][n_times][n_samples]
  * (times[i-1], times[i]] the solution is the Lagrange interpolant through rows i-m+1 .. i, which is what a saveat grid would
  * have returned there.  0: no polynomial for this row (the initial state; every row of a run on a saveat grid).  [n_times] */
 const int32_t* ch_result_dense_points(const ch_result*);
+/* The values of ch_result_values STILL IN HBM, same layout [n_obs][n_times][n_samples], for a device-side consumer — the result gather of
+ * a sharded sweep (src/sweeps.jl:471-502 collects the per-point solutions on the host; here RCCL moves the rows GPU to GPU).  *ptr is a
+ * device pointer on the context's GPU, owned by the circuit and valid until the next call on that circuit or ch_circuit_free.
+ * CH_ERR_UNSUPPORTED (and *ptr = NULL) when the rows are not kept: the host stepper ran, the row buffer was drained in batches, or an
+ * observable is a known node / merged node / eliminated branch (those are filled in on the host). */
+int ch_result_device_values(const ch_result*, const double** ptr, int64_t* n_doubles);
 const double* ch_result_final_state(const ch_result*); /* [n_samples][n_mna] at the last time   */
 int ch_result_stats(const ch_result*, ch_stats*);
 int ch_result_status(const ch_result*);           /* CH_OK or CH_ERR_*                          */

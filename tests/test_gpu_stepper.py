@@ -443,3 +443,54 @@ def test_continuous_corners_keep_the_history_jumps_restart(E, O):
     assert rcj == 0
     after = lambda tb: tj[np.searchsorted(tj, tb, side="right")] - tb          # noqa: E731  first step behind a break point
     assert after(1e-9) < 1e-13 and after(2e-9) > 1e-12 and after(3e-9) > 1e-12, (after(1e-9), after(2e-9), after(3e-9))
+
+
+HBM_ROWS_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+assert torch.cuda.is_available()          # torch's HIP runtime first, as in bench.py: the engine then binds to the runtime already loaded
+torch.cuda.set_device(0)
+sys.path.insert(0, sys.argv[1])
+from cedarsim_jl_amd import dc_opts, tran_opts, gather_sharded_device
+from cedarsim_jl_amd import bsim4_params as B4
+from cedarsim_jl_amd.engine import EngineCircuit, load_library
+from cedarsim_jl_amd.workloads import dff_array
+load_library()
+c = dff_array(1, observe="q")
+c.observe_node("q_neg")
+slots = [c.slot("nfet_06v0", "vth0")]
+base = c.models[c.model_names.index("nfet_06v0")]
+e = EngineCircuit(c)
+S = 16
+e.set_samples(S)
+e.set_params(slots, [list(base[B4.PARAM_INDEX["vth0"]] * (1.0 + 0.01 * np.arange(S)))])
+sv = np.linspace(0.0, 3e-7, 61)
+rc, t, v, _, st = e.tran(0.0, 3e-7, tran_opts(abstol=1e-5, reltol=1e-5, saveat=sv, dc=dc_opts(abstol=1e-14)))
+assert rc == 0 and st["stepper"] == 2 and st["device_rows"] is not None and st["device_rows"].shape == v.shape
+dev = torch.as_tensor(st["device_rows"], device="cuda")
+assert dev.data_ptr() == st["device_rows"].ptr, "a view, not a copy"
+assert np.array_equal(dev.cpu().numpy(), v)
+y = (dev * 2.0).sum().item()               # torch kernels read the engine's buffer
+assert abs(y - 2.0 * v.sum()) <= 1e-9 * abs(y)
+c2 = dff_array(1, observe="q")
+c2.observe_node("vdd")                     # a known node: evaluated on the host, so the rows are not offered
+rc2, _, _, _, st2 = EngineCircuit(c2).tran(0.0, 1e-7, tran_opts(abstol=1e-4, reltol=1e-4, saveat=np.linspace(0, 1e-7, 11)))
+assert rc2 == 0 and st2["device_rows"] is None
+print("HBM_ROWS_OK")
+"""
+
+
+def test_result_rows_stay_in_hbm_for_a_device_side_gather(tmp_path):
+    """`ch_result_device_values`: after a device-stepper transient the rows [n_obs][n_times][n_samples] are still in HBM; a torch CUDA
+    tensor made from them without a copy (`__cuda_array_interface__`) equals the host result and torch kernels can read it — the
+    single-rank half of the RCCL gather of a sharded sweep (bench.py `config4_sharded_sweep`).  Results whose observables are
+    filled in on the host (a known node) are not offered.  In a process of its own, torch first: torch ships its own HIP runtime, and
+    the engine must bind to the one already loaded for the pointer to mean anything to torch (the order bench.py uses)."""
+    import subprocess
+    import sys
+    script = tmp_path / "hbm_rows.py"
+    script.write_text(HBM_ROWS_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HBM_ROWS_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
