@@ -67,6 +67,27 @@ if only in ("all", "config4"):
                       "block_iterations": st["n_block_iters"], "block_iterations_per_second": st["n_block_iters"] / el,
                       "samples_passing_reference_gate": int(ok.all(axis=0).sum())}
     out["config4_mc8192"] = {"samples": S, **res}
+if only in ("all", "config4", "config4_sweep"):
+    # config 4 THROUGH the reference's sweep surface: an explicit 8192-point Monte-Carlo TandemSweep of one DFF (src/sweeps.jl:278-290,
+    # 473-480), CircuitSweep learns the name -> table-entry map from a handful of builds (setup reported apart) and runs ONE batched solve
+    from cedarsim_jl_amd import CircuitSweep
+    from cedarsim_jl_amd.workloads import dff_mc_builder, mc_tandem_sweep
+    S = 8192
+    build, names = dff_mc_builder(observe=("q",))
+    t0 = time.perf_counter()
+    sweep = mc_tandem_sweep(S)
+    draw_s = time.perf_counter() - t0
+    res = {}
+    for label in ("first_call", "second_call"):
+        cs = CircuitSweep(build, sweep)
+        t0 = time.perf_counter()
+        rc, t, rows, st = cs.tran_arrays((0.0, 7e-7), abstol=1e-4, reltol=1e-4, dc_abstol=1e-14, saveat=np.array(DFF_CHECK_TIMES))
+        el = time.perf_counter() - t0
+        ok = np.abs(rows[:, 0, :] - np.array(DFF_CHECK_Q)[None, :]) < 1e-3
+        res[label] = {"rc": rc, "wall_seconds_incl_setup": el, "setup": cs.setup, "dc_seconds": st["dc_seconds"], "stepper": st["stepper"], "stepper_mode": st["stepper_mode"],
+                      "block_iterations": st["n_block_iters"], "block_iterations_per_second_of_the_solve": st["n_block_iters"] / max(1e-12, el - cs.setup["seconds"]),
+                      "samples_passing_reference_gate": int(ok.all(axis=1).sum())}
+    out["config4_mc8192_through_CircuitSweep"] = {"samples": S, "swept_names": list(names), "draw_seconds": draw_s, **res}
 if only in ("all", "config4_share"):
     S = 1024
     c = dff_array(1)
@@ -114,7 +135,7 @@ if only in ("all", "coupled"):
         e = EngineCircuit(c)
         opts = tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-12), saveat=np.array(DFF_CHECK_TIMES))
         entry = {}
-        for label in ("torn", "sparse"):
+        for label in os.environ.get("CEDARHIP_COUPLED_FORMS", "torn,sparse").split(","):
             if label == "sparse":
                 os.environ["CEDARHIP_NO_TEAR"] = "1"
             else:

@@ -57,6 +57,13 @@ if /opt/rocm/bin/hipcc -O2 -fPIC -shared --offload-arch=gfx950 -o /tmp/libprobe.
   timeout -k 10 120 /tmp/probe_main; echo "control (no cedarhip), plain: status $?" | tee "$OUT/${TAG}_exit_probe.log"
   timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_exit_probe_stats" -o run -- /tmp/probe_main > /dev/null 2>&1; echo "control (no cedarhip), under rocprofv3 --kernel-trace --stats: status $?" | tee -a "$OUT/${TAG}_exit_probe.log"
 fi
+if [ "$2" = "coupled" ] || [ "$3" = "coupled" ]; then
+  # the coupled 1024-DFF array on the general sparse path (subtree form), dominant kernel sp3_group_kernel
+  export CEDARHIP_COUPLED_TILES=1024 CEDARHIP_COUPLED_FORMS=sparse
+  profile "${TAG}_coupled" "scripts/bench_configs.py coupled (1024-DFF array behind 1-ohm rails, sparse path only, two transients); per-launch averages" "sp3_group_kernel" \
+    "$ROOT/scripts/bench_configs.py" coupled -- "$ROOT/scripts/bench_configs.py" coupled
+  unset CEDARHIP_COUPLED_TILES CEDARHIP_COUPLED_FORMS
+fi
 if [ "$2" = "config5" ]; then
   profile "${TAG}_cfg5" "scripts/bench_configs.py config5 (128 ASAP7 BSIM-CMG inverters, two transients); per-launch averages" "tran_persistent_kernel" \
     "$ROOT/scripts/bench_configs.py" config5 -- "$ROOT/scripts/bench_configs.py" config5
