@@ -1339,7 +1339,27 @@ struct ch_circuit {
       }
     }
     const size_t wave_d = persist_wave_doubles(wg_consts);
-    const size_t lds = (max_cd + (max_ci + 1) / 2 + PW * P_NREC + P_NREC + 4 + P_SCR + PW * wave_d) * sizeof(double);
+    size_t lds = (max_cd + (max_ci + 1) / 2 + PW * P_NREC + P_NREC + 4 + P_SCR + PW * wave_d) * sizeof(double);
+    // compiled Verilog-A devices: room for the workgroup's parameter and constant blocks in LDS (what the blocks of the heaviest
+    // component need, without counting shared blocks once; the kernel shares them and stops staging when the arena is full)
+    size_t va_arena = 0;
+    if (A.wide && std::getenv("CEDARHIP_VA_NO_LDS") == nullptr) {
+      size_t worst = 0;
+      for (int cpt = 0; cpt < A.n_comp; ++cpt) {
+        size_t need = 0;
+        for (int i = 0; i < A.comp_ndev[cpt]; ++i) {
+          const EDev& e = A.edev[A.comp_dofs[cpt] + i];
+          if (e.kind != K_VA) continue;
+          const int mod = dev[e.hdev].ipar[0];
+          need += (size_t)((va_gen::param_doubles(mod) + 1) & ~1) + (size_t)((va_gen::cache_doubles(mod) + 1) & ~1);
+        }
+        worst = std::max(worst, need);
+      }
+      const size_t room = lds < 148 * 1024 ? (148 * 1024 - lds) / sizeof(double) : 0;
+      va_arena = std::min(worst * (size_t)bpw, room);
+      lds += va_arena * sizeof(double);
+      if (std::getenv("CEDARHIP_DEBUG_STEPPER")) std::fprintf(stderr, "[stepper] compiled devices: %zu doubles per block, LDS arena %zu doubles, workgroup LDS %zu bytes\n", worst, va_arena, lds);
+    }
     // wave pairs share the device evaluation by function when every block has the same class and at most 32 evaluation slots
     const bool pair = A.wide ? wide_split
                              : (A.classes.size() == 1 && h_cms[0].nslots <= 32 && std::getenv("CEDARHIP_PERSIST_NOPAIR") == nullptr);
@@ -1363,7 +1383,7 @@ struct ch_circuit {
     PersistArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.a = base;
     pa.a.mode = MODE_TRAN; pa.a.maxit = nmaxit; pa.a.abstol = o.abstol; pa.a.reltol = o.reltol; pa.a.newton_tol = 0.1; pa.a.active = nullptr; pa.a.gshunt = 0.0;
-    pa.bpw = bpw; pa.wide_l = wide_l; pa.wide_other = wide_other;
+    pa.bpw = bpw; pa.wide_l = wide_l; pa.wide_other = wide_other; pa.va_arena = (int)va_arena;
     pa.nblk = nblk; pa.n_wg = n_wg; pa.red_max = (S > 1 || own_steps) ? 1 : 0; pa.wave_doubles = (int)wave_d;
     pa.t1 = t1; pa.dtmin = dtmin; pa.dtmax = dtmax; pa.first_frac = 1e-3; pa.kmax = kmax; pa.max_steps = max_steps;
     pa.bps = d_pbps.p; pa.nbp = (int)bps.size(); pa.saveat = d_psave.p; pa.n_saveat = o.n_saveat;

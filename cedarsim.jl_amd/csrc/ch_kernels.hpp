@@ -239,6 +239,43 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
   if (WIDE) widen_stamp(st, st_final);
 }
 
+// A compiled Verilog-A lane slot of the device-resident stepper, resolved ONCE per transient: module, the instance's parameter and
+// constant blocks (global memory, or the workgroup's LDS copies: tran_persistent_kernel stages them — a BSIM-CMG evaluation reads
+// some hundred of these constants one dependent load at a time, an L2 round trip each when they stay in global memory),
+// multiplicity and terminals.  mod < 0: not such a slot (eval_slot<true> handles it).
+struct WideMeta {
+  int mod, dl;
+  const double* P; const double* C;
+  double m;
+  int t[NTERM];
+};
+__device__ __forceinline__ WideMeta load_wide_meta(const EvalCtx& a, int s, int dofs, int slot) {
+  WideMeta q;
+  q.mod = -1; q.dl = 0; q.P = nullptr; q.C = nullptr; q.m = 0.0;
+#pragma unroll
+  for (int k = 0; k < NTERM; ++k) q.t[k] = -1;
+  if (slot < 0) return q;
+  const int dl = (slot >> 4) & 0x01ffffff, d = dofs + dl;
+  if (a.dkind[d] != K_VA) return q;
+  q.dl = dl; q.mod = a.dcls_local[d];
+  q.P = a.vapar + a.dsrc[d]; q.C = a.vacache + a.dvac[d];
+  q.m = a.dmult[(long)a.dhdev[d] * a.Spar + (a.Spar > 1 ? s : 0)];
+#pragma unroll
+  for (int k = 0; k < NTERM; ++k) q.t[k] = a.dterm[NTERM * d + k];
+  return q;
+}
+template <bool LDS>
+__device__ __forceinline__ void eval_wide_cached(const WideMeta& q, const EvalCtx& a, int slot, const double* xl, int uofs, const double* kvl, double* stage) {
+  double vv[NTERM];
+#pragma unroll
+  for (int k = 0; k < NTERM; ++k) { const int t = q.t[k]; vv[k] = t >= 0 ? xl[t - uofs] : kvl[-t - 1]; }
+  const va::Env env{a.temp_k, a.gmin};
+  const int part = (slot & (1 << 29)) ? ((slot >> 30) & 1) : -1;
+  double* st = stage + (size_t)q.dl * StampLayout<true>::STRIDE;
+  if (LDS) va_gen::stamp_dir_lds(q.mod, (va::lds_cptr)q.P, (va::lds_cptr)q.C, vv, env, q.m, slot & 7, (slot & 8) != 0, part, st);
+  else va_gen::stamp_dir_c(q.mod, q.P, q.C, vv, env, q.m, slot & 7, (slot & 8) != 0, part, st);
+}
+
 // What one lane of the device-resident stepper evaluates, loaded ONCE per transient: a lane keeps its device for the whole time
 // span, so the device tables are not read again inside the time loop (in the per-attempt kernel they cost a chain of three
 // dependent global loads per evaluation, and seven table pointers held in scalar registers across the BSIM4 code).

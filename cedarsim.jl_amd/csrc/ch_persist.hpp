@@ -59,6 +59,7 @@ struct PersistArgs {
   int bpw;                    // blocks per workgroup: PW, or 2 (one wave pair per CU, the other two waves idle) to spread few, heavy blocks over more CUs
   int wide_l, wide_other;     // WIDE + PAIR: lanes of one half of the block's split compiled devices, and its other (unsplit) evaluation slots
   int wave_doubles;           // LDS doubles per wave region
+  int va_arena;               // WIDE: LDS doubles behind the wave regions for the workgroup's copies of its compiled devices' parameter and constant blocks
   double t1, dtmin, dtmax, first_frac;
   int kmax, max_steps, nbp, n_saveat;
   const double* bps; const double* saveat;   // bps: [nbp times | nbp codes (< 0: the sources jump there; else the length of the source segment starting there)]; per workgroup the same pair at its offset
@@ -539,7 +540,55 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
         else if (role == 0 && sq - p.wide_l < p.wide_other) wslot = slots_h[64 + p.wide_l + (sq - p.wide_l)];
       }
     } else if (live && lane < cm.nslots) wslot = slots[lane];
-  } else
+  }
+  // WIDE: the lane's compiled device resolved once, and the workgroup's distinct parameter / constant blocks copied to LDS (first
+  // come first served while the arena lasts; a block that does not fit stays in global memory).  One wave after the other, so that
+  // the directory needs no atomics; wave-uniform control flow throughout.
+  WideMeta wmeta = load_wide_meta(ectx, PAIR ? s_h : s, PAIR ? dofs_h : dofs, WIDE ? wslot : -1);
+  bool va_lds = false;   // workgroup-uniform: every compiled device of this workgroup reads its blocks from LDS (stamp_dir_lds)
+  if (WIDE && p.va_arena > 0) {
+    __shared__ unsigned long long s_va_ptr[32];
+    __shared__ int s_va_ofs[32];
+    __shared__ int s_va_n, s_va_top, s_va_fail;
+    double* arena = summ + P_NREC + 4 + P_SCR + (size_t)PW * p.wave_doubles;
+    if (tid == 0) { s_va_n = 0; s_va_top = 0; s_va_fail = 0; }
+    __syncthreads();
+    const double* staged[2] = {nullptr, nullptr};
+    for (int w = 0; w < PW; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          const double* g = which ? wmeta.C : wmeta.P;
+          const int n = wmeta.mod < 0 ? 0 : (which ? va_gen::cache_doubles(wmeta.mod) : va_gen::param_doubles(wmeta.mod));
+          bool pend = n > 0;
+          for (;;) {
+            const unsigned long long bal = __ballot(pend);
+            if (!bal) break;
+            const int srcl = __ffsll((long long)bal) - 1;
+            const unsigned long long gp = ((unsigned long long)(unsigned)__shfl((int)((unsigned long long)g >> 32), srcl) << 32) | (unsigned)__shfl((int)(unsigned long long)g, srcl);
+            const int nn = __shfl(n, srcl);
+            const int ndir = s_va_n, top = s_va_top;
+            int ofs = -1;
+            for (int e = 0; e < ndir; ++e) if (s_va_ptr[e] == gp) ofs = s_va_ofs[e];
+            if (ofs < 0 && ndir < 32 && top + nn <= p.va_arena) {
+              ofs = top;
+              const double* gsrc = (const double*)gp;
+              for (int i = lane; i < nn; i += 64) arena[top + i] = gsrc[i];
+              lds_fence();
+              if (lane == 0) { s_va_ptr[ndir] = gp; s_va_ofs[ndir] = top; s_va_n = ndir + 1; s_va_top = top + ((nn + 1) & ~1); }
+              lds_fence();
+            }
+            if (ofs < 0 && lane == 0) s_va_fail = 1;
+            if (pend && (unsigned long long)g == gp) { staged[which] = ofs >= 0 ? arena + ofs : nullptr; pend = false; }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    va_lds = s_va_fail == 0;
+    if (va_lds && wmeta.mod >= 0) { wmeta.P = staged[0] ? staged[0] : arena; wmeta.C = staged[1] ? staged[1] : arena; }   // a block of zero doubles is never read
+  }
+  if (!WIDE)
   {
     int slot = -1;
     if (PAIR) { const int sq = lane & 31; if (live_h && sq < cm.nslots) slot = slots_h[sq]; }
@@ -682,7 +731,10 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
           const int d0 = pf[2], d1 = pf[3];
           if (!bbd && ((d0 && d1) || pair_broken)) break;
           if (!(half ? d1 : d0)) {
-            if (WIDE) { if (wslot >= 0) eval_slot<true>(ectx, s_h, dofs_h, wslot, xl_h, uofs_h, kvl, svl, pl_h, st_h); }
+            if (WIDE) {
+              if (wmeta.mod >= 0) { if (va_lds) eval_wide_cached<true>(wmeta, ectx, wslot, xl_h, uofs_h, kvl, st_h); else eval_wide_cached<false>(wmeta, ectx, wslot, xl_h, uofs_h, kvl, st_h); }
+              else if (wslot >= 0) eval_slot<true>(ectx, s_h, dofs_h, wslot, xl_h, uofs_h, kvl, svl, pl_h, st_h);
+            }
             else {
             if (role == 0) eval_cached<0>(smeta, gmin_h, xl_h, kvl, svl, pl_h, st_h);
             if (role == 1 ? (p.pair_dbg & 1) == 0 : (p.pair_dbg & 1) == 1) eval_cached<1>(smeta, gmin_h, xl_h, kvl, svl, pl_h, st_h);
@@ -695,7 +747,10 @@ __global__ __launch_bounds__(PW * 64, 1) void tran_persistent_kernel(const Persi
             if (done_own) continue;
           }
         } else {
-        if (WIDE) { if (wslot >= 0) eval_slot<true>(ectx, s, dofs, wslot, xl, uofs, kvl, svl, pl, st); }
+        if (WIDE) {
+          if (wmeta.mod >= 0) { if (va_lds) eval_wide_cached<true>(wmeta, ectx, wslot, xl, uofs, kvl, st); else eval_wide_cached<false>(wmeta, ectx, wslot, xl, uofs, kvl, st); }
+          else if (wslot >= 0) eval_slot<true>(ectx, s, dofs, wslot, xl, uofs, kvl, svl, pl, st);
+        }
         else if (!bbd || live) eval_cached<-1>(smeta, gmin_h, xl, kvl, svl, pl, st);
         lds_fence();
         P_STAMP(4);   // device evaluation

@@ -30,6 +30,13 @@
 
 namespace va {
 
+// pointer to a parameter / constant block that a kernel has copied into LDS (generated eval<R, PART, lds_cptr>)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(3))) double* lds_cptr;
+#else
+typedef const double* lds_cptr;
+#endif
+
 struct Env {
   double temperature;  // kelvin: $temperature (src/va_env.jl:123)
   double gmin;         // $simparam("gmin")

@@ -809,7 +809,9 @@ class ModuleGen:
         out += param_decls + var_decls("double") + ["  (void)env; (void)P; (void)C;"] + S + ["}"]
         # PART: -1 everything; 0 the resistive sums I[] only; 1 the charge sums Q[] only — two half-evaluations on two wavefronts
         # (the engine's function split of a compiled device: what a half does not store, the compiler drops)
-        out.append("template <class R, int PART> VA_HD_NOINLINE void eval(const double* P, const double* C, const R* V, const va::Env& env, R* I, R* Q) {")
+        # CP: the pointer type of the parameter and constant blocks — `const double*`, or va::lds_cptr when the caller has staged them
+        # into LDS (then every P[i] / C[i] is a ds_read that waits on the LDS counter alone instead of a flat load behind every scratch store)
+        out.append("template <class R, int PART, class CP = const double*> VA_HD_NOINLINE void eval(CP P, CP C, const R* V, const va::Env& env, R* I, R* Q) {")
         out.append("  VA_KEEP_RETURN_ADDRESS;")
         out += param_decls + var_decls("R")
         out.append("  (void)env; (void)V; (void)P; (void)C;")
@@ -960,6 +962,22 @@ def generate_header(modules, source_tag=""):
     out.append("}")
     out.append("static const int N_CACHE[] = {%s};" % (", ".join(str(g.n_cache) for g in gens) or "0"))
     out.append("constexpr int MAX_CACHE = %d;" % max([1] + [g.n_cache for g in gens]))
+    out.append("// doubles of module `mod`'s parameter block [values | given flags] and of its constant block (device-side sizes: a kernel")
+    out.append("// that stages the blocks of its instances into LDS)")
+    out.append("VA_HD int param_doubles(int mod) {")
+    out.append("  switch (mod) {")
+    for i, g in enumerate(gens):
+        out.append("    case %d: return %d;" % (i, 2 * len(g.m.params)))
+    out.append("    default: return 0;")
+    out.append("  }")
+    out.append("}")
+    out.append("VA_HD int cache_doubles(int mod) {")
+    out.append("  switch (mod) {")
+    for i, g in enumerate(gens):
+        out.append("    case %d: return %d;" % (i, g.n_cache))
+    out.append("    default: return 0;")
+    out.append("  }")
+    out.append("}")
     out.append("// Per-instance constants of module `mod`: C[0 .. N_CACHE[mod]) from the parameter block and the temperature")
     out.append("VA_HD_NOINLINE void setup(int mod, const double* P, const va::Env& env, double* C) {")
     out.append("  switch (mod) {")
@@ -1023,6 +1041,33 @@ def generate_header(modules, source_tag=""):
         out.append("      }")
         out.append("    } break;")
     out.append("    default: break;")
+    out.append("  }")
+    out.append("}")
+    out.append("")
+    out.append("// stamp_dir_c with the parameter and constant blocks in LDS (tran_persistent_kernel stages them once per transient): the large")
+    out.append("// models get an instantiation that reads them with LDS instructions, every other module goes through the generic pointers")
+    out.append("VA_HD_NOINLINE void stamp_dir_lds(int mod, va::lds_cptr P, va::lds_cptr C, const double* v, const va::Env& env, double m, int dir, bool first, int part, double* st) {")
+    out.append("  switch (mod) {")
+    for i, g in enumerate(gens):
+        mo = g.m
+        if len(mo.params) < 64:
+            continue
+        nt, nd = len(mo.nodes), len(g.ddx_nodes)
+        R = "va::VD<1, double>" if nd == 0 else "va::VD<1, va::VD<%d, double>>" % nd
+        out.append("    case %d: {" % i)
+        out.append("      typedef %s R;" % R)
+        out.append("      R V[%d], I[%d], Q[%d];" % (nt, nt, nt))
+        for k, node in enumerate(mo.nodes):
+            dk = g.ddx_nodes.index(node) if node in g.ddx_nodes else -1
+            out.append("      V[%d] = va::seed1(v[%d], dir == %d, %d, (R*)nullptr);" % (k, k, k, dk))
+        out.append("      if (part != 1) m_%s::eval<R, 0, va::lds_cptr>(P, C, V, env, I, Q);" % mo.name)
+        out.append("      if (part != 0) m_%s::eval<R, 1, va::lds_cptr>(P, C, V, env, I, Q);" % mo.name)
+        out.append("      for (int k = 0; k < %d; ++k) {" % nt)
+        out.append("        if (part != 1) { if (first) st[k] = m * va::val(I[k]); st[16 + k * 8 + dir] = m * va::val(I[k].d[0]); }")
+        out.append("        if (part != 0) { if (first) st[8 + k] = m * va::val(Q[k]); st[80 + k * 8 + dir] = m * va::val(Q[k].d[0]); }")
+        out.append("      }")
+        out.append("    } break;")
+    out.append("    default: stamp_dir_c(mod, (const double*)P, (const double*)C, v, env, m, dir, first, part, st); break;")
     out.append("  }")
     out.append("}")
     out.append("")
