@@ -25,6 +25,9 @@ profile() {   # tag, description, kernel name ("auto": the bench's stepper kerne
     echo "pmc pass $name done ($tag)"
   done
   (cd "$ROOT" && python3 scripts/pmc_summary.py "$OUT" "$tag" "$what" "$kern")
+  # the raw per-dispatch CSVs (tens of MB for a launch-heavy workload) stay on the box: gpurun copies back at most 64 MiB
+  find "$OUT" -path "$OUT/${tag}_pmc_*" -name "*.csv" -size +256k -delete 2>/dev/null || true
+  find "$OUT/${tag}_stats" -name "*kernel_trace.csv" -size +256k -delete 2>/dev/null || true
 }
 profile "$TAG" "bench.py --steps 1 --warmup 0 (1024-DFF array transient); per-launch averages" auto \
   "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-skew -- "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-skew
@@ -37,26 +40,7 @@ if gcc -std=c99 -O2 -I "$ROOT/include" "$ROOT/examples/c_abi_demo.c" -L "$ROOT/c
   timeout -k 10 120 /tmp/c_abi_demo_prof > "$OUT/${TAG}_c_demo_plain.log" 2>&1 || echo "plain C client ended with status $?"
   unset CEDARHIP_DEMO_MAPS
 fi
-# Control experiment for that exit-time SIGSEGV: a 10-line HIP shared library (one kernel, one launch, everything freed) behind a plain-C
-# main, nothing of cedarhip in the process.  If IT also ends with status 139 under rocprofv3 and 0 without, the crash belongs to the
-# profiler's teardown against any hipcc-built shared object (its compiler-generated fat-binary unregistration at exit), not to this library.
-cat > /tmp/probe_lib.hip <<'PROBE'
-#include <hip/hip_runtime.h>
-__global__ void probe_k(int* p) { *p = 42; }
-extern "C" int probe_run(void) {
-  int* d = nullptr; int h = 0;
-  if (hipMalloc((void**)&d, sizeof(int)) != hipSuccess) return 2;
-  hipLaunchKernelGGL(probe_k, dim3(1), dim3(1), 0, 0, d);
-  if (hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 3;
-  (void)hipFree(d);
-  return h == 42 ? 0 : 1;
-}
-PROBE
-printf 'int probe_run(void);\nint main(void) { return probe_run(); }\n' > /tmp/probe_main.c
-if /opt/rocm/bin/hipcc -O2 -fPIC -shared --offload-arch=gfx950 -o /tmp/libprobe.so /tmp/probe_lib.hip > /dev/null 2>&1 && gcc -O2 /tmp/probe_main.c -L/tmp -lprobe -Wl,-rpath,/tmp -o /tmp/probe_main; then
-  timeout -k 10 120 /tmp/probe_main; echo "control (no cedarhip), plain: status $?" | tee "$OUT/${TAG}_exit_probe.log"
-  timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_exit_probe_stats" -o run -- /tmp/probe_main > /dev/null 2>&1; echo "control (no cedarhip), under rocprofv3 --kernel-trace --stats: status $?" | tee -a "$OUT/${TAG}_exit_probe.log"
-fi
+bash "$ROOT/scripts/exit_probe.sh" "$TAG"
 if [ "$2" = "coupled" ] || [ "$3" = "coupled" ]; then
   # the coupled 1024-DFF array on the general sparse path (subtree form), dominant kernel sp3_group_kernel
   export CEDARHIP_COUPLED_TILES=1024 CEDARHIP_COUPLED_FORMS=sparse
