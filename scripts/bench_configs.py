@@ -174,5 +174,5 @@ if only in ("all", "config5"):
                                    "newton_iters_per_sec": st["nnonliniter"] / el, "block_iterations": st["n_block_iters"],
                                    "roofline": {"bound": "hbm", "algorithmic_bytes_per_instance_evaluation": 792, "achieved_GBps": kb / max(1e-12, st["step_kernel_seconds"]) / 1e9,
                                                 "frac_of_8TBps": kb / max(1e-12, st["step_kernel_seconds"]) / 8e12,
-                                                "limiter": "fp64 issue of the generated dual-number code (about 22 k fp64 instructions per evaluation and direction after the setup/eval split; 1.5 kB scratch per lane), 128 workgroups on 256 CUs"}}
+                                                "limiter": "single-wave instruction issue of the generated dual-number code: about 17.5 k instructions per evaluation half and Newton iteration (12 k VALU, 5.6 k of them fp64; profiles/r03_cfg5_wait_counters.json) at about 7 cycles each; 128 blocks on 64 CUs, one persistent launch"}}
 print(json.dumps(out))
