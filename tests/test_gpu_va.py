@@ -384,3 +384,55 @@ def test_temperature_sweep_of_a_compiled_device_as_samples(E):
         c1 = ckt(T)
         rc1, x1, _, _ = E(c1).dc(dc_opts(abstol=1e-13))
         assert rc1 == 0 and abs(x1[0][c1._n("a") - 1] - va[k]) < 1e-9, (T, x1[0][c1._n("a") - 1], va[k])
+
+
+def test_compiled_device_constants_in_lds_equal_global_memory(E, monkeypatch):
+    """The device-resident stepper copies the parameter and constant blocks of a workgroup's compiled instances into LDS and evaluates
+    the large models through `eval<R, PART, va::lds_cptr>` (ch_persist.hpp, `PersistArgs::va_arena`); `CEDARHIP_VA_NO_LDS=1` keeps the
+    blocks in global memory (the same generated function over generic pointers).  Same steps, same waveform — on an array that
+    leaves waves without a block (6 blocks: two workgroups of two pairs, the second half empty) and on a batch of samples with their
+    own temperatures (one constant block per sample and instance, shared parameter blocks)."""
+    import os
+    from cedarsim_jl_amd.workloads import CMG_TSPAN, cmg_inverter_array
+    if "bsimcmg" not in load_modules()[1]:
+        pytest.skip("bsimcmg was not in the model library build")
+    cards = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "asap7_tt_lvt_cards.json")))["cards"]
+    ts = np.linspace(0, 1e-7, 41)
+    opts = lambda: tran_opts(abstol=1e-6, reltol=1e-6, saveat=ts, dc=dc_opts(abstol=1e-10, tran_mode=1), stepper="device")  # noqa: E731
+
+    def both(make):
+        out = []
+        for no_lds in (False, True):
+            if no_lds:
+                monkeypatch.setenv("CEDARHIP_VA_NO_LDS", "1")
+            else:
+                monkeypatch.delenv("CEDARHIP_VA_NO_LDS", raising=False)
+            eng = make()
+            rc, t, v, xf, st = eng.tran(CMG_TSPAN[0], 1e-7, opts())
+            assert rc == 0 and st["stepper"] == 2
+            out.append((v.copy(), st["naccept"], st["nreject"], st["nnonliniter"]))
+        monkeypatch.delenv("CEDARHIP_VA_NO_LDS", raising=False)
+        (v0, *c0), (v1, *c1) = out
+        assert c0 == c1, (c0, c1)
+        assert np.abs(v0 - v1).max() < 1e-12
+        return v0
+
+    v = both(lambda: E(cmg_inverter_array(6, cards, amp=0.2, observe="q")))
+    assert v[0, :, 0].max() - v[0, :, 0].min() > 0.05                   # the output moves
+    assert np.abs(v[:, :, 0] - v[0:1, :, 0]).max() < 1e-12              # identical tiles
+
+    temps = np.array([-20.0, 0.0, 27.0, 60.0, 100.0, 125.0])
+
+    def batch():
+        c = cmg_inverter_array(1, cards, amp=0.2, observe="q")
+        e = E(c)
+        e.set_samples(len(temps))
+        e.set_params([c.slot("temp")], [temps])
+        return e
+    vb = both(batch)
+    assert vb.shape[2] == len(temps)
+    assert len(set(np.round(vb[0, -1, :], 7))) == len(temps)            # every sample really ran at its own temperature
+    c1 = cmg_inverter_array(1, cards, amp=0.2, observe="q")
+    c1.temp = 100.0
+    rc1, t1, v1, _, _ = E(c1).tran(CMG_TSPAN[0], 1e-7, opts())
+    assert rc1 == 0 and np.abs(v1[0, :, 0] - vb[0, :, 4]).max() < 1e-5
