@@ -425,9 +425,10 @@ def test_compiled_device_constants_in_lds_equal_global_memory(E, monkeypatch):
 
     def batch():
         c = cmg_inverter_array(1, cards, amp=0.2, observe="q")
+        slot = c.slot("temp")          # before the engine sees the description
         e = E(c)
         e.set_samples(len(temps))
-        e.set_params([c.slot("temp")], [temps])
+        e.set_params([slot], [temps])
         return e
     vb = both(batch)
     assert vb.shape[2] == len(temps)
