@@ -66,7 +66,7 @@ class ChDcOpts(C.Structure):
 class ChTranOpts(C.Structure):
     _fields_ = [("abstol", C.c_double), ("reltol", C.c_double), ("max_order", C.c_int32), ("dtmin", C.c_double),
                 ("dtmax", C.c_double), ("dt0", C.c_double), ("max_steps", C.c_int32), ("newton_maxiters", C.c_int32),
-                ("n_saveat", C.c_int32), ("saveat", _pf64), ("dc", ChDcOpts), ("skip_dc", C.c_int32), ("stepper", C.c_int32)]
+                ("n_saveat", C.c_int32), ("saveat", _pf64), ("dc", ChDcOpts), ("skip_dc", C.c_int32), ("stepper", C.c_int32), ("step_control", C.c_int32)]
 
 
 class ChInfo(C.Structure):
@@ -92,9 +92,12 @@ def dc_opts(abstol=1e-10, maxiters=200, n_restarts=10, seed=10, tran_mode=False,
 
 
 def tran_opts(abstol=1e-6, reltol=1e-3, max_order=5, dtmin=0.0, dtmax=0.0, dt0=0.0, max_steps=0,
-              newton_maxiters=10, saveat=None, dc=None, skip_dc=False, stepper="auto"):
-    """stepper: "auto" | "host" | "device" — where the sequential step controller runs (include/cedarhip.h CH_STEPPER_*)."""
+              newton_maxiters=10, saveat=None, dc=None, skip_dc=False, stepper="auto", step_control="auto"):
+    """stepper: "auto" | "host" | "device" — where the sequential step controller runs (include/cedarhip.h CH_STEPPER_*).
+    step_control: "auto" | "shared" — "shared" keeps ONE step sequence and error norm over the whole circuit / batch even on a
+    `saveat` grid (CH_STEPS_SHARED: what a single IDA() over the whole system does, src/sweeps.jl:456)."""
     o = ChTranOpts()
+    o.step_control = {"auto": 0, "shared": 1}[step_control] if isinstance(step_control, str) else int(step_control)
     o.stepper = {"auto": 0, "host": 1, "device": 2}[stepper] if isinstance(stepper, str) else int(stepper)
     o.abstol, o.reltol, o.max_order = abstol, reltol, max_order
     o.dtmin, o.dtmax, o.dt0, o.max_steps, o.newton_maxiters = dtmin, dtmax, dt0, max_steps, newton_maxiters

@@ -1254,7 +1254,7 @@ struct ch_circuit {
   // the output is wanted on a common `saveat` grid: independent blocks ARE independent problems, a shared step size only makes
   // each pay for the others' break points and dilutes its local error in the array-wide norm.  (Not for the bordered form.)
   bool persist_own_steps(const ch_tran_opts& o) const {
-    return ((A.n_comp == 1 && S > 1) || (S == 1 && A.n_comp > 1 && A.nb == 0 && !A.wide)) && o.n_saveat > 0 && std::getenv("CEDARHIP_LOCKSTEP") == nullptr;
+    return ((A.n_comp == 1 && S > 1) || (S == 1 && A.n_comp > 1 && A.nb == 0 && !A.wide)) && o.n_saveat > 0 && o.step_control != CH_STEPS_SHARED && std::getenv("CEDARHIP_LOCKSTEP") == nullptr;
   }
   size_t persist_wave_doubles(bool wg_consts) const {
     const size_t n_ent = wg_consts ? (size_t)P_MAXSRC : A.known.size() + n_dev_src();

@@ -65,7 +65,7 @@ struct ChDcOpts
 end
 struct ChTranOpts
     abstol::Float64; reltol::Float64; max_order::Int32; dtmin::Float64; dtmax::Float64; dt0::Float64
-    max_steps::Int32; newton_maxiters::Int32; n_saveat::Int32; saveat::Ptr{Float64}; dc::ChDcOpts; skip_dc::Int32; stepper::Int32
+    max_steps::Int32; newton_maxiters::Int32; n_saveat::Int32; saveat::Ptr{Float64}; dc::ChDcOpts; skip_dc::Int32; stepper::Int32; step_control::Int32
 end
 struct ChStats
     nf::Int64; njacs::Int64; nfactors::Int64; nsolve::Int64; nnonliniter::Int64; nnonlinconvfail::Int64
@@ -469,10 +469,12 @@ function build(sim; slots = NTuple{3,Int32}[], pass = stamp_extract(sim))
     circ, Int(desc.n_obs), names
 end
 
-function run_tran(circ, n_obs, n_samples, tspan, abstol, reltol, initializealg, saveat)
+# shared_steps = true: CH_STEPS_SHARED — one step sequence and error norm over the whole system even on a saveat grid, i.e. what the
+# ONE IDA() integrator of `tran!` (src/sweeps.jl:456) does; the default lets independent blocks / samples take their own steps there
+function run_tran(circ, n_obs, n_samples, tspan, abstol, reltol, initializealg, saveat; shared_steps::Bool = false)
     sv = Float64.(collect(saveat))
     opts = ChTranOpts(abstol, reltol, Int32(5), 0.0, 0.0, 0.0, Int32(0), Int32(10), Int32(length(sv)), isempty(sv) ? Ptr{Float64}(C_NULL) : pointer(sv),
-                      dcopts(initializealg; tran_mode = initializealg isa CedarTranOp), Int32(0), Int32(0))
+                      dcopts(initializealg; tran_mode = initializealg isa CedarTranOp), Int32(0), Int32(0), Int32(shared_steps ? 1 : 0))
     res = Ref{Ptr{Cvoid}}(C_NULL)
     rc = GC.@preserve sv ccall((:ch_tran, lib), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Ref{ChTranOpts}, Ref{Ptr{Cvoid}}), circ, tspan[1], tspan[2], opts, res)
     res[] == C_NULL && throw(CedarSim.CedarError(last_error()))     # an exception barrier answered (CH_ERR_NOMEM / CH_ERR_INTERNAL)
@@ -488,10 +490,12 @@ function run_tran(circ, n_obs, n_samples, tspan, abstol, reltol, initializealg, 
     rc, t, u, pts, st[]
 end
 
-function SciMLBase.__solve(prob::DAEProblem, ::CedarHIPAlg; abstol = 1e-6, reltol = 1e-3, initializealg = CedarDCOp(), saveat = Float64[], kwargs...)
+# shared_steps = true asks for what one IDA() over the whole system does on a saveat grid too (one step sequence, one error norm);
+# the default lets structurally independent blocks of the circuit step on their own there (a stricter, per-block norm)
+function SciMLBase.__solve(prob::DAEProblem, ::CedarHIPAlg; abstol = 1e-6, reltol = 1e-3, initializealg = CedarDCOp(), saveat = Float64[], shared_steps = false, kwargs...)
     circ, n_obs, names = build(prob.p)
     try
-        rc, t, u, pts, st = run_tran(circ, n_obs, 1, prob.tspan, abstol, reltol, initializealg, saveat)
+        rc, t, u, pts, st = run_tran(circ, n_obs, 1, prob.tspan, abstol, reltol, initializealg, saveat; shared_steps)
         CedarHIPSolution(prob, t, u, pts, names, retcode(rc), st, 1)
     finally
         ccall((:ch_circuit_free, lib), Cvoid, (Ptr{Cvoid},), circ)
@@ -499,11 +503,11 @@ function SciMLBase.__solve(prob::DAEProblem, ::CedarHIPAlg; abstol = 1e-6, relto
 end
 "tran!(circ, tspan, CedarHIPAlg(); abstol, reltol): the reference's `tran!(circ, tspan)` (src/sweeps.jl:450-456) without DAECompiler —
 the circuit closure is stamped and solved; index the result with `HipSystem()`: `sol[HipSystem().node_q]`."
-function tran!(circ, tspan, ::CedarHIPAlg; abstol = 1e-6, reltol = 1e-3, initializealg = CedarDCOp(), saveat = Float64[])
+function tran!(circ, tspan, ::CedarHIPAlg; abstol = 1e-6, reltol = 1e-3, initializealg = CedarDCOp(), saveat = Float64[], shared_steps = false)
     sim = circ isa AbstractSim ? circ : DefaultSim(circ)
     c, n_obs, names = build(sim)
     try
-        rc, t, u, pts, st = run_tran(c, n_obs, 1, tspan, abstol, reltol, initializealg, saveat)
+        rc, t, u, pts, st = run_tran(c, n_obs, 1, tspan, abstol, reltol, initializealg, saveat; shared_steps)
         CedarHIPSolution(nothing, t, u, pts, names, retcode(rc), st, 1)
     finally
         ccall((:ch_circuit_free, lib), Cvoid, (Ptr{Cvoid},), c)

@@ -200,6 +200,11 @@ typedef struct ch_tran_opts {
   int32_t skip_dc;         /* 1: start from dc.x0 as given (u0 passed by the caller, test/common.jl:36-43) */
   int32_t stepper;         /* CH_STEPPER_AUTO (default): device-resident controller where the circuit qualifies, host otherwise;
                               CH_STEPPER_HOST / CH_STEPPER_DEVICE force one (DEVICE fails with CH_ERR_UNSUPPORTED when it cannot run) */
+  int32_t step_control;    /* CH_STEPS_AUTO (default): with a saveat grid, independent blocks / samples take their own steps under their
+                              own error norm (above).  CH_STEPS_SHARED: ONE step sequence and ONE error norm over the whole circuit /
+                              batch whatever the output grid — the answer of a single IDA() integrator over the whole system
+                              (src/sweeps.jl:456), and the same controller a run without saveat uses: results of the two are then
+                              comparable point for point */
 } ch_tran_opts;
 
 /* Where the sequential step controller of ch_tran runs (the policy is the same): on the host with one kernel
@@ -207,6 +212,7 @@ typedef struct ch_tran_opts {
  * accept/reject/order/step decision is taken from a grid-wide reduction by every wavefront identically). */
 enum { CH_STEPPER_AUTO = 0, CH_STEPPER_HOST = 1, CH_STEPPER_DEVICE = 2 };
 enum { CH_MODE_LOCKSTEP = 1, CH_MODE_OWN_STEPS = 2, CH_MODE_BORDERED = 3 };
+enum { CH_STEPS_AUTO = 0, CH_STEPS_SHARED = 1 };
 
 typedef struct ch_ctx ch_ctx;
 typedef struct ch_circuit ch_circuit;

@@ -494,3 +494,30 @@ def test_result_rows_stay_in_hbm_for_a_device_side_gather(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "HBM_ROWS_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+def test_shared_step_control_on_a_saveat_grid_is_the_run_without_one(E):
+    """`ch_tran_opts.step_control = CH_STEPS_SHARED` (a `saveat` grid alone used to change the error norm):
+    independent blocks on a `saveat` grid keep ONE step sequence and ONE error norm — the single integrator of
+    `solve(prob, IDA(); …)` over the whole system (src/sweeps.jl:456).  The result on the grid is then the dense output of the run
+    WITHOUT a grid (same steps), on both controllers; the default takes per-block steps there (mode 2) and may differ by the
+    tolerance."""
+    from cedarsim_jl_amd.api import Solution
+    rng = np.random.default_rng(7)
+    c = dff_array(6, skew=rng.uniform(0.0, 50e-12, 6), observe="q")   # six tiles that are NOT identical: per-block steps really differ
+    e = E(c)
+    sv = np.linspace(0.0, 7e-7, 141)[1:-1]
+    kw = dict(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14))
+    rc, t, v, _, st = e.tran(0.0, 7e-7, tran_opts(stepper="device", **kw))
+    assert rc == 0 and st["stepper"] == 2 and st["stepper_mode"] == 1
+    for stepper in ("device", "host"):
+        rc1, t1, v1, _, st1 = e.tran(0.0, 7e-7, tran_opts(saveat=sv, stepper=stepper, step_control="shared", **kw))
+        assert rc1 == 0 and (st1["naccept"], st1["nreject"]) == (st["naccept"], st["nreject"]), (stepper, st1["naccept"], st["naccept"])
+        if stepper == "device":
+            assert st1["stepper"] == 2 and st1["stepper_mode"] == 1
+        sol = Solution(c, t, {o: v[k, :, 0] for k, o in enumerate(c.obs)}, None, rc, st)
+        for k in range(6):
+            assert np.max(np.abs(sol(sv, idxs="x%d.q" % k) - v1[k, :, 0])) < 1e-8, (stepper, k)
+    rc2, t2, v2, _, st2 = e.tran(0.0, 7e-7, tran_opts(saveat=sv, stepper="device", **kw))
+    assert rc2 == 0 and st2["stepper_mode"] == 2                       # the default on a grid: per-block steps
+    assert np.max(np.abs(v2 - v1)) < 0.05 * 5.0                        # the same waveforms within what the tolerance allows at the edges
