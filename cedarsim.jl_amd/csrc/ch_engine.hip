@@ -294,7 +294,7 @@ struct ch_circuit {
   SparsePlan plan[2];           // [0] DC (alpha0 = 0), [1] transient
   struct PlanDev { DevBuf<int> prow, pcol, a2lu, diag_pos, lvl_ptr, lvl_rows, ulvl_ptr, ulvl_rows, lrow_ptr, l_pos, l_k, l_upd_ptr, upd_dst, upd_src, urow_ptr, u_pos, u_col;
                    DevBuf<int> lu2a, la_pos, la_diag, lb_dst, lb_sptr, lb_l, lb_u, lb_d, fl_rows, bl_rows; DevBuf<double> LUv, Lv;
-                   DevBuf<int> s3_blob, s3_ptr, s3_topa, s3_topr; DevBuf<double> s3_schur, s3_xT; bool s3 = false; } plan_dev[2];
+                   DevBuf<int> s3_blob, s3_ptr, s3_topa, s3_topr; DevBuf<double> s3_schur, s3_xT, s3_base, s3_sum; DevBuf<unsigned> s3_cnt; bool s3 = false; } plan_dev[2];
   DevBuf<int> sp_dflag;
   DevBuf<double> sp_part;   // [S][8][SP_NP] per-workgroup partial reductions of the O(n) passes (ch_sparse.hpp)
   DevBuf<double> sp_hpart, sp_hrow;   // slices of the heavy assembly items [S][items][SP_HB][2] and of the heavy rows of the charge update [S][rows][SP_RB]
@@ -805,6 +805,8 @@ struct ch_circuit {
         HIPCHK(pd.s3_topr.upload(tr, st)); }
       HIPCHK(pd.s3_schur.alloc((size_t)S * (size_t)std::max(1, T.nT * T.nT + T.nT) * (size_t)T.n_groups));
       HIPCHK(pd.s3_xT.alloc((size_t)S * (size_t)std::max(1, T.nT)));
+      HIPCHK(pd.s3_base.alloc((size_t)S * (size_t)std::max(1, T.nT * T.nT + T.nT)));
+      HIPCHK(pd.s3_sum.alloc((size_t)S * (size_t)std::max(1, T.nT * T.nT + T.nT))); HIPCHK(pd.s3_cnt.alloc((size_t)S));
       const int lds3 = T.max_nv * 8 + T.max_blob * 4;
       HIPCHK(hipFuncSetAttribute((const void*)sp3_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds3, 64 * 1024)));
       HIPCHK(hipFuncSetAttribute((const void*)sp3_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds3, 64 * 1024)));
@@ -829,12 +831,12 @@ struct ch_circuit {
     const SparseDev d = sparse_dev(which);
     if (plan_dev[which].s3) {
       PlanDev& pd = plan_dev[which]; const SubtreePlan& T = P.sub;
-      Sp3Dev q; q.blob = pd.s3_blob.p; q.blob_ptr = pd.s3_ptr.p; q.top_a_idx = pd.s3_topa.p; q.top_rows = pd.s3_topr.p; q.schur = pd.s3_schur.p; q.xT = pd.s3_xT.p;
+      Sp3Dev q; q.blob = pd.s3_blob.p; q.blob_ptr = pd.s3_ptr.p; q.top_a_idx = pd.s3_topa.p; q.top_rows = pd.s3_topr.p; q.schur = pd.s3_schur.p; q.xT = pd.s3_xT.p; q.top_base = pd.s3_base.p; q.top_sum = pd.s3_sum.p; q.top_cnt = pd.s3_cnt.p;
       q.n_groups = T.n_groups; q.nT = T.nT; q.max_nv = T.max_nv;
       const unsigned lds3 = (unsigned)(T.max_nv * 8 + T.max_blob * 4);
-      hipLaunchKernelGGL(sp3_reset_kernel, dim3(1, (unsigned)n_work), dim3(64), 0, st, d, wl);
+      hipLaunchKernelGGL(sp3_reset_kernel, dim3(1, (unsigned)n_work), dim3(64), 0, st, d, wl, q);
       hipLaunchKernelGGL(sp3_group_kernel, dim3((unsigned)T.n_groups, (unsigned)n_work), dim3(64), lds3, st, d, wl, q);
-      hipLaunchKernelGGL(sp3_top_kernel, dim3(1, (unsigned)n_work), dim3(256), 0, st, d, wl, q);
+      hipLaunchKernelGGL(sp3_top_kernel, dim3(SP3_TOP_WG, (unsigned)n_work), dim3(256), 0, st, d, wl, q);
       hipLaunchKernelGGL(sp3_back_kernel, dim3((unsigned)T.n_groups, (unsigned)n_work), dim3(64), lds3, st, d, wl, q);
       n_launch += 4;
       return;

@@ -404,11 +404,23 @@ struct Sp3Dev {
   const int* top_a_idx; const int* top_rows;   // top_rows: [nT] pivot index | [nT] rhs index prow[.] | [nT] dx index pcol[.]
   double* schur;                            // [S][nT*nT + nT][n_groups]: entry-major, so that the top kernel sums a contiguous run per entry
   double* xT;                               // [S][nT]
+  double* top_base;                         // [S][nT*nT + nT]: A's own top entries and right-hand sides, gathered by sp3_reset_kernel
+  double* top_sum;                          // [S][nT*nT + nT]: base + the groups' contributions, one entry per wavefront of sp3_top_kernel
+  unsigned* top_cnt;                        // [S]: workgroups of sp3_top_kernel that have delivered their entries (zeroed by sp3_reset_kernel)
   int n_groups, nT, max_nv;
 };
-__global__ void sp3_reset_kernel(const SparseDev d0, const int* act) {   // the singular flags of this factorisation
+// the singular flags of this factorisation; and the top block's own entries A_TT and right-hand sides gathered into one contiguous
+// run (two dependent loads each — index, then value — that the top kernel would otherwise wait for in its own chain)
+__global__ void sp3_reset_kernel(const SparseDev d0, const int* act, const Sp3Dev q) {
   const SparseDev d = sp_pick(d0, act);
-  if (threadIdx.x == 0) { d.flag[0] = 0; d.dflag[0] = 0; }
+  if (threadIdx.x == 0) { d.flag[0] = 0; d.dflag[0] = 0; q.top_cnt[d.s] = 0u; }
+  const int nT = q.nT, ne = nT * nT + nT;
+  for (int j = threadIdx.x; j < ne; j += blockDim.x) {
+    double b;
+    if (j < nT * nT) { const int ai = q.top_a_idx[j]; b = ai >= 0 ? d.Aval[ai] : 0.0; }
+    else b = d.rhs[q.top_rows[nT + (j - nT * nT)]];
+    q.top_base[(size_t)d.s * ne + j] = b;
+  }
 }
 // one wavefront per group: load; ONE step per pivot — every lane takes fused updates a_ic -= (a_ik / u_kk) u_kc and
 // y_i -= (a_ik / u_kk) y_k (nothing a step reads is written by it: one barrier per pivot); Schur contributions.
@@ -455,53 +467,99 @@ __global__ __launch_bounds__(64) void sp3_group_kernel(const SparseDev d0, const
   if (sing && lane == 0) { d.flag[0] = 1; d.dflag[0] = 1; }
 }
 // the top block: S = A_TT + sum over groups (fixed order), right-hand side likewise, dense LU with partial pivoting, x_T.
-// grid (1, samples), 256 threads.
+// grid (SP3_TOP_WG, samples), 256 threads.  The sums are spread over the grid — ONE wavefront per entry, 16 loads in flight per lane,
+// fixed order (lane, wavefront tree): for the coupled 1024-DFF array nT = 6, i.e. 42 entries x 1024 groups = 344 KB, which a single
+// workgroup pulled through one CU in six dependent batches (29-34 us).  The workgroup that delivers last (an agent-scope counter;
+// which one it is does not enter the result: every entry is summed by exactly one wavefront) factors and solves the top system:
+// one wavefront, an element of the trailing block per lane and elimination step.
+constexpr int SP3_TOP_WG = 16;
+// lanes of ONE wavefront hand values to each other through LDS: s_waitcnt lgkmcnt(0), and the compiler keeps the accesses on their sides
+#define SP_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__device__ __forceinline__ double sp_ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sp_st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __global__ __launch_bounds__(256) void sp3_top_kernel(const SparseDev d0, const int* act, const Sp3Dev q) {
   const SparseDev d = sp_pick(d0, act);
   __shared__ double S[16 * 17];
-  __shared__ double base[16 * 17];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nT = q.nT, ne = nT * nT + nT;
+  __shared__ int s_flag[2];   // [0]: this workgroup delivered last; [1]: singular
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nT = q.nT, ne = nT * nT + nT, ld = nT + 1;
   const double* so = q.schur + (size_t)d.s * ne * q.n_groups;
-  // A's own entries and the right-hand sides: one thread each, all loads in flight together
-  for (int j = t; j < ne; j += 256) {
-    if (j < nT * nT) { const int ai = q.top_a_idx[j]; base[j] = ai >= 0 ? d.Aval[ai] : 0.0; }
-    else base[j] = d.rhs[q.top_rows[nT + (j - nT * nT)]];
-  }
-  __syncthreads();
-  // one wavefront per entry: the groups' contributions, lanes striding over the groups, fixed-order tree
-  for (int j = wave; j < ne; j += 4) {
+  const double* tb = q.top_base + (size_t)d.s * ne;
+  double* ts = q.top_sum + (size_t)d.s * ne;
+  // requested before anything is waited for (a memory round trip is ~2 us on a cold L2): flag, the index of this lane's result
+  const int sing0 = d.dflag[0];
+  const int dxi = t < nT ? q.top_rows[2 * nT + t] : 0;
+  for (int j = blockIdx.x * 4 + wave; j < ne; j += SP3_TOP_WG * 4) {
+    const double bj = tb[j];
     double a = 0.0;
-    for (int g0 = lane; g0 < q.n_groups; g0 += 64 * 8) {   // eight loads in flight per lane (one at a time, each waited for its own
-      double v[8];                                          // memory round trip: 68 us for 1024 groups), summed in a fixed order
+    for (int g0 = lane; g0 < q.n_groups; g0 += 64 * 16) {
+      double v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int g = g0 + 64 * u; v[u] = g < q.n_groups ? so[(size_t)j * q.n_groups + g] : 0.0; }
+      for (int u = 0; u < 16; ++u) { const int g = g0 + 64 * u; v[u] = g < q.n_groups ? so[(size_t)j * q.n_groups + g] : 0.0; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += v[u];
+      for (int u = 0; u < 16; u += 4) a += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
     }
     a = sp2_wave_sum(a);
-    if (lane == 0) { if (j < nT * nT) S[(j / nT) * (nT + 1) + (j % nT)] = base[j] + a; else S[(j - nT * nT) * (nT + 1) + nT] = base[j] + a; }
+    if (lane == 0) sp_st_agent(ts + j, bj + a);
+  }
+  __threadfence();
+  __syncthreads();
+  if (t == 0) {
+    const unsigned before = __hip_atomic_fetch_add(q.top_cnt + d.s, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_flag[0] = before == (unsigned)(gridDim.x - 1);
+    s_flag[1] = sing0;
   }
   __syncthreads();
-  if (t == 0 && nT > 0) {
-    bool sing = d.dflag[0] != 0;
-    const int ld = nT + 1;
-    for (int k = 0; k < nT && !sing; ++k) {
-      int bi = k; double best = fabs(S[k * ld + k]);
-      for (int i = k + 1; i < nT; ++i) if (fabs(S[i * ld + k]) > best) { best = fabs(S[i * ld + k]); bi = i; }
+  if (!s_flag[0]) return;
+  __threadfence();
+  for (int j = t; j < ne; j += 256) {
+    const double v = sp_ld_agent(ts + j);
+    if (j < nT * nT) S[(j / nT) * ld + (j % nT)] = v; else S[(j - nT * nT) * ld + nT] = v;
+  }
+  __syncthreads();
+  if (wave == 0 && nT > 0 && !sing0) {
+    bool sing = false;
+    for (int k = 0; k < nT; ++k) {
+      // pivot: the largest |S[i][k]|, i >= k (the lowest row on ties)
+      double best = (lane >= k && lane < nT) ? fabs(S[lane * ld + k]) : -1.0;
+      int bi = lane;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      best = __shfl(best, 0); bi = __shfl(bi, 0);
       if (!(best > 0.0) || !(best < 1e300)) { sing = true; break; }
-      if (bi != k) for (int j = 0; j <= nT; ++j) { const double tmp = S[k * ld + j]; S[k * ld + j] = S[bi * ld + j]; S[bi * ld + j] = tmp; }
-      for (int i = k + 1; i < nT; ++i) { const double l = S[i * ld + k] / S[k * ld + k]; for (int j = k + 1; j <= nT; ++j) S[i * ld + j] -= l * S[k * ld + j]; }
+      if (bi != k && lane <= nT) { const double tmp = S[k * ld + lane]; S[k * ld + lane] = S[bi * ld + lane]; S[bi * ld + lane] = tmp; }
+      SP_WAVE_LDS_SYNC();   // one wavefront, LDS in order — the swapped rows are what the next reads see
+      const int rows = nT - 1 - k, cols = nT - k;   // trailing rows k+1..nT-1, columns k+1..nT (the right-hand side is column nT)
+      const double pk = S[k * ld + k];
+      double upd[5]; int pos[5];                      // (nT-1) * nT <= 240 elements: at most four per lane (+1 spare)
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int idx = lane + 64 * r;
+        pos[r] = -1; upd[r] = 0.0;
+        if (idx < rows * cols) {
+          const int i = k + 1 + idx / cols, c = k + 1 + idx % cols;
+          pos[r] = i * ld + c;
+          upd[r] = S[pos[r]] - (S[i * ld + k] / pk) * S[k * ld + c];
+        }
+      }
+      SP_WAVE_LDS_SYNC();
+#pragma unroll
+      for (int r = 0; r < 5; ++r) if (pos[r] >= 0) S[pos[r]] = upd[r];
+      SP_WAVE_LDS_SYNC();
     }
-    if (sing) { d.flag[0] = 1; d.dflag[0] = 1; }
-    else for (int k = nT - 1; k >= 0; --k) {
-      double sx = S[k * ld + nT];
-      for (int j = k + 1; j < nT; ++j) sx -= S[k * ld + j] * S[j * ld + nT];
-      sx /= S[k * ld + k];
-      S[k * ld + nT] = sx;
+    if (sing) { if (lane == 0) { d.flag[0] = 1; d.dflag[0] = 1; s_flag[1] = 1; } }
+    else for (int k = nT - 1; k >= 0; --k) {          // column-oriented: x_k, then every row above takes its share
+      const double xk = S[k * ld + nT] / S[k * ld + k];
+      SP_WAVE_LDS_SYNC();
+      if (lane == 0) S[k * ld + nT] = xk;
+      if (lane < k) S[lane * ld + nT] -= S[lane * ld + k] * xk;
+      SP_WAVE_LDS_SYNC();
     }
   }
   __syncthreads();
-  if (t < nT && !d.dflag[0]) { const double x = S[t * (nT + 1) + nT]; q.xT[(size_t)d.s * nT + t] = x; d.dx[q.top_rows[2 * nT + t]] = x; }
+  if (t < nT && !s_flag[1]) { const double x = S[t * ld + nT]; q.xT[(size_t)d.s * nT + t] = x; d.dx[dxi] = x; }
 }
 // backward substitution of the groups with x_T, column-oriented: first y_i -= u_iT x_T for every top unknown, then the pivots in
 // descending order: x_k = y_k / u_kk, y_i -= u_ik x_k for the rows of the group that hold column k.  grid (n_groups, samples), 64 threads.

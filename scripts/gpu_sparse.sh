@@ -12,3 +12,4 @@ export CEDARHIP_COUPLED_TILES=1024 TMPDIR=/tmp
 ROOT=$(pwd); cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_coupled_prof -o run -- python3 $ROOT/scripts/bench_configs.py coupled > $ROOT/gpurun_out/${TAG}_coupled_prof.log 2>&1
 cut -c1-150 $ROOT/gpurun_out/${TAG}_coupled_prof/run_kernel_stats.csv | head -22
+find $ROOT/gpurun_out/${TAG}_coupled_prof -name "*kernel_trace.csv" -size +256k -delete
