@@ -192,11 +192,27 @@ def config4_sharded_sweep(ctx, rank, world, dist, backend, samples_per_rank=1024
     # `__cuda_array_interface__`: no host round trip); the gathered tensor is copied to the host once afterwards, for the checks below,
     # and that copy is timed apart.  Anything else (the gloo rehearsal, rows the engine did not keep on the device): host rows.
     how, d2h_s = "host rows -> device staging -> all_gather -> host", None
-    t0 = time.perf_counter()
     drows = None if plumbing_only else stats.get("device_rows")
-    if dist is not None and dev == "cuda" and drows is not None:
+    # The zero-copy view is taken — and the choice of path agreed between the ranks (one tiny all_reduce: a rank that took another
+    # path than its peers would hang their collective) — BEFORE the timed gather; a rank that cannot wrap its buffer sends everybody
+    # to the host-rows path, and says why.
+    local_dev, view_note = None, None
+    if dist is not None and dev == "cuda":
+        ok_here = 0
+        if drows is not None:
+            try:
+                local_dev = torch.as_tensor(drows, device="cuda")            # zero-copy view of the engine's buffer [n_obs, n_save, samples]
+                ok_here = 1 if (tuple(local_dev.shape) == tuple(drows.shape) and local_dev.dtype == torch.float64) else 0
+            except Exception as ex:  # noqa: BLE001
+                view_note = "%s: %s" % (type(ex).__name__, ex)
+        flag = torch.tensor([ok_here], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            local_dev = None
+            how = "host rows -> device staging -> all_gather -> host (no device view of the engine's rows on some rank%s)" % ((": " + view_note) if view_note else "")
+    t0 = time.perf_counter()
+    if local_dev is not None:
         from cedarsim_jl_amd import gather_sharded_device
-        local_dev = torch.as_tensor(drows, device="cuda")                    # zero-copy view of the engine's buffer [n_obs, n_save, samples]
         full_dev = gather_sharded_device(local_dev, S_total, rank, world)    # [n_obs, n_save, S_total] on every rank
         torch.cuda.synchronize()
         gather_s = time.perf_counter() - t0
