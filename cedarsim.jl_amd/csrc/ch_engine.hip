@@ -2475,6 +2475,24 @@ static int ch_debug_poison_lds_impl(ch_ctx* ctx) {
   if (e != hipSuccess) { ctx->err = std::string("poison_lds: ") + hipGetErrorString(e); return CH_ERR_DEVICE; }
   return CH_OK;
 }
+// test hook: the device's own exp / ln (ch_fpmath.hpp through va::v_exp, va::v_ln and the BSIM4 code's flog) over a vector
+__global__ void debug_math_kernel(int which, int n, const double* x, double* y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  y[i] = which == 0 ? va::v_exp(x[i]) : which == 1 ? va::v_ln(x[i]) : flog(x[i]);
+}
+static int ch_debug_math_impl(ch_ctx* ctx, int32_t which, int32_t n, const double* x, double* y) {
+  if (!ctx || which < 0 || which > 2 || n < 1 || !x || !y) return CH_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  double *dx = nullptr, *dy = nullptr;
+  if (hipMalloc((void**)&dx, (size_t)n * sizeof(double)) != hipSuccess || hipMalloc((void**)&dy, (size_t)n * sizeof(double)) != hipSuccess) { (void)hipFree(dx); return CH_ERR_NOMEM; }
+  hipError_t e = hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) { hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, which, n, (const double*)dx, dy); e = hipStreamSynchronize(ctx->stream); }
+  if (e == hipSuccess) e = hipMemcpy(y, dy, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(dy);
+  if (e != hipSuccess) { ctx->err = std::string("debug_math: ") + hipGetErrorString(e); return CH_ERR_DEVICE; }
+  return CH_OK;
+}
 static int ch_bench_fp64_impl(ch_ctx* ctx, int32_t iters, double* tflops_out) {
   if (!ctx || iters < 1 || !tflops_out) return CH_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
@@ -2585,6 +2603,7 @@ int ch_noise(ch_circuit* c, const ch_dc_opts* o, int32_t out_kind, int32_t out_i
 int ch_bench_triad(ch_ctx* ctx, int64_t n, int32_t iters, double* gbps_out) { return guard_rc(ctx, [&] { return ch_bench_triad_impl(ctx, n, iters, gbps_out); }); }
 int ch_bench_fp64(ch_ctx* ctx, int32_t iters, double* tflops_out) { return guard_rc(ctx, [&] { return ch_bench_fp64_impl(ctx, iters, tflops_out); }); }
 int ch_debug_poison_lds(ch_ctx* ctx) { return guard_rc(ctx, [&] { return ch_debug_poison_lds_impl(ctx); }); }
+int ch_debug_math(ch_ctx* ctx, int32_t which, int32_t n, const double* x, double* y) { return guard_rc(ctx, [&] { return ch_debug_math_impl(ctx, which, n, x, y); }); }
 int ch_va_eval(ch_ctx* ctx, int32_t id, const double* par, const double* v, double temperature_k, double gmin, double* st_out) {
   return guard_rc(ctx, [&] { return ch_va_eval_impl(ctx, id, par, v, temperature_k, gmin, st_out); });
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     "ch_result_n_times", "ch_result_times", "ch_result_dense_points", "ch_result_device_values", "ch_result_values", "ch_result_final_state", "ch_result_stats",
     "ch_result_status", "ch_result_free", "ch_eval", "ch_ac", "ch_noise", "ch_mos_eval", "ch_mos_eval_quad", "ch_bsim4_npar", "ch_bsim4_param_name",
     "ch_bsim4_param_ignored", "ch_version", "ch_bench_triad", "ch_bench_fp64", "ch_va_n_modules", "ch_va_find", "ch_va_module_name", "ch_va_module_info",
-    "ch_va_node_name", "ch_va_param_name", "ch_va_eval", "ch_va_n_opvars", "ch_va_opvar_name", "ch_va_opvars", "ch_debug_poison_lds",
+    "ch_va_node_name", "ch_va_param_name", "ch_va_eval", "ch_va_n_opvars", "ch_va_opvar_name", "ch_va_opvars", "ch_debug_poison_lds", "ch_debug_math",
 ]
 
 _lib = None
@@ -142,6 +142,17 @@ class Context:
         if rc != 0:
             raise RuntimeError("ch_va_opvars failed: %s" % self.last_error())
         return {self.L.ch_va_opvar_name(int(module_id), k).decode(): float(out[k]) for k in range(n)}
+
+    def debug_math(self, which, x):
+        """Test hook: the device's own exp (which=0), ln (1) and the BSIM4 code's ln (2) over a vector (ch_debug_math)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        pf = C.POINTER(C.c_double)
+        self.L.ch_debug_math.argtypes = [C.c_void_p, C.c_int32, C.c_int32, pf, pf]
+        rc = self.L.ch_debug_math(self.h, int(which), len(x), x.ctypes.data_as(pf), y.ctypes.data_as(pf))
+        if rc != 0:
+            raise RuntimeError("ch_debug_math failed: %s" % self.last_error())
+        return y
 
     def poison_lds(self):
         """Test hook: leave every CU's LDS full of garbage (ch_debug_poison_lds)."""

@@ -437,3 +437,30 @@ def test_compiled_device_constants_in_lds_equal_global_memory(E, monkeypatch):
     c1.temp = 100.0
     rc1, t1, v1, _, _ = E(c1).tran(CMG_TSPAN[0], 1e-7, opts())
     assert rc1 == 0 and np.abs(v1[0, :, 0] - vb[0, :, 4]).max() < 1e-5
+
+
+def test_device_exp_and_ln_accuracy(ctx):
+    """The device functions take exp / ln from cedarsim.jl_amd/csrc/ch_fpmath.hpp (coefficients in __constant__ tables, read through
+    scalar loads): within 2 ulp of libm over the whole range, and libm's answers at the special values — what `va_env.jl:35-47`
+    (NaNMath) asks of ln, and what IEEE asks of exp."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate((rng.uniform(-745.0, 709.7, 20000), rng.uniform(-2.0, 2.0, 20000), rng.uniform(-1e-8, 1e-8, 2000),
+                        np.array([0.0, -0.0, 1.0, -1.0, 709.782712893384, 709.79, 720.0, 1e6, -745.2, -746.0, -1e6, 0.5 * np.log(2.0), -0.5 * np.log(2.0)])))
+    y = ctx.debug_math(0, x)
+    with np.errstate(over="ignore"):
+        ref = np.exp(x)
+    ok = np.isfinite(ref) & (ref > 0)
+    ulp = np.abs(y[ok] - ref[ok]) / np.spacing(ref[ok])
+    assert ulp.max() <= 2.0, (ulp.max(), x[ok][np.argmax(ulp)])
+    assert np.array_equal(y[~ok], ref[~ok])                       # overflow -> inf, deep underflow -> 0
+    sp = ctx.debug_math(0, np.array([np.inf, -np.inf, np.nan]))
+    assert sp[0] == np.inf and sp[1] == 0.0 and np.isnan(sp[2])
+    for which in (1, 2):                                          # compiled Verilog-A's ln, the BSIM4 code's ln
+        xl = np.concatenate((np.exp(rng.uniform(-700.0, 700.0, 20000)), rng.uniform(0.5, 2.0, 20000), 1.0 + rng.uniform(-1e-6, 1e-6, 2000),
+                             np.array([1.0, 2.0, 0.5, np.sqrt(0.5), np.sqrt(2.0), 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308])))
+        yl = ctx.debug_math(which, xl)
+        rl = np.log(xl)
+        err = np.abs(yl - rl) / np.maximum(np.spacing(np.abs(rl)), 1e-17)     # near ln 1 = 0 an absolute 1e-17 stands in for the ulp
+        assert err.max() <= 2.0, (which, err.max(), xl[np.argmax(err)])
+        sp = ctx.debug_math(which, np.array([0.0, -1.0, np.inf, np.nan]))
+        assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and np.isnan(sp[3])
