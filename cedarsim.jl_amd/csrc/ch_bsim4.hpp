@@ -19,7 +19,6 @@
 #include <cstdint>
 
 #include "../../include/cedarhip.h"
-#include "ch_fpmath.hpp"
 
 #if defined(__HIPCC__)
 #define CH_HD __host__ __device__
@@ -343,22 +342,26 @@ template <int N> CH_D DN<N> operator/(DN<N> a, double b) { return a * frcp(b); }
 template <int N> CH_D DN<N> operator/(double a, DN<N> b) { return recip(b) * a; }
 template <int N> CH_D DN<N> chain(DN<N> a, double f, double fp) { DN<N> r; r.v = f; for (int i = 0; i < N; ++i) r.p[i] = a.p[i] * fp; return r; }
 template <int N> CH_D DN<N> dsqrt(DN<N> a) { const double s = fsqrt(a.v); return chain(a, s, 0.5 * frcp(s)); }
-// exp with its coefficients in a __constant__ table (ch_fpmath.hpp) on the device, the library's on the host
-CH_D double fexp(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return chfp::exp_tab(x);
-#else
-  return exp(x);
-#endif
-}
-template <int N> CH_D DN<N> dexp(DN<N> a) { const double e = fexp(a.v); return chain(a, e, e); }
+template <int N> CH_D DN<N> dexp(DN<N> a) { const double e = exp(a.v); return chain(a, e, e); }
 // Natural logarithm for positive finite normal arguments (every use below: junction terms, smoothing functions and
 // mobility powers).  x = m·2^e with m in [sqrt(1/2), sqrt(2)); s = (m−1)/(m+1); ln m = 2s(1 + s²/3 + … + s¹⁸/19),
 // |s| ≤ 0.1716 so the truncation error is 2e-17.  ≈ 28 instructions against 118 for the library log on gfx950
 // (76 of them fp64); 0, negative, NaN and +inf arguments are handled by a final selection.
 CH_D double flog(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const double r = chfp::ln_pos_tab(x);   // coefficients from a __constant__ table through scalar loads (ch_fpmath.hpp)
+  double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? 2.0 * m : m;
+  e = lo ? e - 1 : e;
+  const double s = (m - 1.0) * frcp(m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 19.0;
+  p = fma(p, z, 1.0 / 17.0); p = fma(p, z, 1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0); p = fma(p, z, 1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, 1.0 / 3.0);
+  const double lm = fma(2.0 * s, p * z, 2.0 * s);
+  const double de = (double)e;
+  const double r = fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
   // special cases by selection (no branch): 0 -> -inf, negative / NaN -> NaN, +inf -> +inf
   return (x > 0.0 && x < __builtin_inf()) ? r : (x == 0.0 ? -__builtin_inf() : (x > 0.0 ? x : __builtin_nan("")));
 #else
@@ -391,7 +394,7 @@ CH_D void diode(double vb, double Is, double Nvtm, double vjm, double IVjm, doub
   if (vb <= vjm) {
     const double t = vb * iN;
     if (t < -k::EXP_TH) { i = Is * (k::MIN_EXP - 1.0) + gmin * vb; g = gmin; }
-    else { const double e = fexp(t); i = Is * (e - 1.0) + gmin * vb; g = Is * e * iN + gmin; }
+    else { const double e = exp(t); i = Is * (e - 1.0) + gmin * vb; g = Is * e * iN + gmin; }
   } else {
     const double s = IVjm * iN;
     i = IVjm - Is + s * (vb - vjm) + gmin * vb; g = s + gmin;
@@ -402,9 +405,9 @@ CH_D void junction(double vb, double cz, double czsw, double czswg, double pb, d
                    double mjsw, double mjswg, double& q, double& c) {
   if (vb < 0.0) {
     q = 0.0; c = 0.0;
-    if (cz > 0.0) { const double a = 1.0 - vb * frcp(pb), s = fexp(-mj * flog(a)); q += pb * cz * (1.0 - a * s) * frcp(1.0 - mj); c += cz * s; }
-    if (czsw > 0.0) { const double a = 1.0 - vb * frcp(pbsw), s = fexp(-mjsw * flog(a)); q += pbsw * czsw * (1.0 - a * s) * frcp(1.0 - mjsw); c += czsw * s; }
-    if (czswg > 0.0) { const double a = 1.0 - vb * frcp(pbswg), s = fexp(-mjswg * flog(a)); q += pbswg * czswg * (1.0 - a * s) * frcp(1.0 - mjswg); c += czswg * s; }
+    if (cz > 0.0) { const double a = 1.0 - vb * frcp(pb), s = exp(-mj * flog(a)); q += pb * cz * (1.0 - a * s) * frcp(1.0 - mj); c += cz * s; }
+    if (czsw > 0.0) { const double a = 1.0 - vb * frcp(pbsw), s = exp(-mjsw * flog(a)); q += pbsw * czsw * (1.0 - a * s) * frcp(1.0 - mjsw); c += czsw * s; }
+    if (czswg > 0.0) { const double a = 1.0 - vb * frcp(pbswg), s = exp(-mjswg * flog(a)); q += pbswg * czswg * (1.0 - a * s) * frcp(1.0 - mjswg); c += czswg * s; }
   } else {
     const double t0 = cz + czsw + czswg, t1 = cz * mj * frcp(pb) + czsw * mjsw * frcp(pbsw) + czswg * mjswg * frcp(pbswg);
     q = vb * (t0 + 0.5 * t1 * vb); c = t0 + t1 * vb;

@@ -2475,7 +2475,7 @@ static int ch_debug_poison_lds_impl(ch_ctx* ctx) {
   if (e != hipSuccess) { ctx->err = std::string("poison_lds: ") + hipGetErrorString(e); return CH_ERR_DEVICE; }
   return CH_OK;
 }
-// test hook: the device's own exp / ln (ch_fpmath.hpp through va::v_exp, va::v_ln and the BSIM4 code's flog) over a vector
+// test hook: the device's own exp / ln (va::v_exp, va::v_ln of va_rt.hpp and the BSIM4 code's flog) over a vector
 __global__ void debug_math_kernel(int which, int n, const double* x, double* y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

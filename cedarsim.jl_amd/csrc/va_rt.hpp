@@ -6,7 +6,6 @@
 // Math follows src/va_env.jl:35-47 (NaNMath: ln/sqrt/pow return NaN outside their domain).
 #pragma once
 #include <cmath>
-#include "ch_fpmath.hpp"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -80,8 +79,22 @@ VA_HD double sqrt_pos(double x) {   // x > 0, finite
   g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
   return __builtin_fma(__builtin_fma(-g, g, x), h, g);
 }
-// ln x for x > 0 finite, exp x: polynomial coefficients from __constant__ tables through scalar loads (ch_fpmath.hpp)
-VA_HD double ln_pos(double x) { return chfp::ln_pos_tab(x); }
+// ln x for x > 0 finite: x = m 2^e, m in [sqrt(1/2), sqrt(2)); s = (m-1)/(m+1); ln m = 2s(1 + s^2/3 + ... + s^18/19), |s| <= 0.1716
+VA_HD double ln_pos(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? 2.0 * m : m;
+  e = lo ? e - 1 : e;
+  const double s = (m - 1.0) * rcp(m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 19.0;
+  p = __builtin_fma(p, z, 1.0 / 17.0); p = __builtin_fma(p, z, 1.0 / 15.0); p = __builtin_fma(p, z, 1.0 / 13.0); p = __builtin_fma(p, z, 1.0 / 11.0);
+  p = __builtin_fma(p, z, 1.0 / 9.0); p = __builtin_fma(p, z, 1.0 / 7.0); p = __builtin_fma(p, z, 1.0 / 5.0); p = __builtin_fma(p, z, 1.0 / 3.0);
+  const double lm = __builtin_fma(2.0 * s, p * z, 2.0 * s);
+  const double de = (double)e;
+  return __builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lm));
+}
 VA_HD double v_div(double a, double b) { return a * rcp(b); }
 #else
 VA_HD double rcp(double x) { return 1.0 / x; }
@@ -120,11 +133,7 @@ template <int N, class S> VA_HD VD<N, S>& operator-=(VD<N, S>& a, const VD<N, S>
 // f(x) with derivative g = f'(x.v): chain rule, generic over the nesting
 template <int N, class S> VA_HD VD<N, S> chain(const VD<N, S>& x, const S& f, const S& g) { VD<N, S> r; r.v = f; for (int i = 0; i < N; ++i) r.d[i] = g * x.d[i]; return r; }
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VA_NO_FAST_MATH)
-VA_HD double v_exp(double x) { return chfp::exp_tab(x); }
-#else
 VA_HD double v_exp(double x) { return ::exp(x); }
-#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VA_NO_FAST_MATH)
 VA_HD double v_ln(double x) { return (x > 0.0 && x < INFINITY) ? ln_pos(x) : (x == 0.0 ? -INFINITY : (x > 0.0 ? x : NAN)); }
 #else
@@ -152,7 +161,7 @@ VA_HD double v_abs(double x) { return ::fabs(x); }
 VA_HD int v_abs(int x) { return x < 0 ? -x : x; }
 VA_HD double v_floor(double x) { return ::floor(x); }
 VA_HD double v_ceil(double x) { return ::ceil(x); }
-VA_HD double v_limexp(double x) { return x < 80.0 ? v_exp(x) : 5.54062238439351e34 * (1.0 + (x - 80.0)); }   // exp(80) = 5.54062238439351e34
+VA_HD double v_limexp(double x) { return x < 80.0 ? ::exp(x) : ::exp(80.0) * (1.0 + (x - 80.0)); }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VA_NO_FAST_MATH)
 // a^b = exp(b ln a) for a > 0 (relative error ~ |b ln a| ulp); the sign of a negative base with an integer exponent is restored;
 // everything else (zero / infinite base, NaN) goes to the library
@@ -160,7 +169,7 @@ VA_HD double v_pow(double a, double b) {
   const double fa = __builtin_fabs(a);
   if (fa > 0.0 && fa < INFINITY && __builtin_fabs(b) < 1e15) {
     if (a < 0.0 && b != ::floor(b)) return NAN;
-    const double p = v_exp(b * ln_pos(fa));
+    const double p = ::exp(b * ln_pos(fa));
     return (a < 0.0 && ::fmod(b, 2.0) != 0.0) ? -p : p;
   }
   return (a < 0.0 && b != ::floor(b)) ? NAN : ::pow(a, b);

@@ -358,9 +358,9 @@ int ch_bench_fp64(ch_ctx*, int32_t iters, double* tflops_out);
 /* ---- test hook: fill the LDS of every CU with a NaN / negative-integer pattern (LDS keeps what the previous kernel left; a
  * kernel that reads LDS it did not stage must not get away with a fresh process's zeros).  No reference counterpart. ---- */
 int ch_debug_poison_lds(ch_ctx*);
-/* Test hook: y[i] = f(x[i]) with the DEVICE's own fp64 functions (cedarsim.jl_amd/csrc/ch_fpmath.hpp: polynomial coefficients in
- * __constant__ tables) — which = 0: exp as compiled Verilog-A code calls it, 1: ln likewise (incl. the special values), 2: the ln
- * of the BSIM4 device code.  Host arrays of n doubles. */
+/* Test hook: y[i] = f(x[i]) with the DEVICE's own fp64 functions (hardware seeds + polynomial / Newton steps instead of the library
+ * sequences: cedarsim.jl_amd/csrc/va_rt.hpp, ch_bsim4.hpp) — which = 0: exp as compiled Verilog-A code calls it, 1: ln likewise
+ * (incl. the special values), 2: the ln of the BSIM4 device code.  Host arrays of n doubles. */
 int ch_debug_math(ch_ctx*, int32_t which, int32_t n, const double* x, double* y);
 
 #ifdef __cplusplus
