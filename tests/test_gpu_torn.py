@@ -289,3 +289,39 @@ def test_return_codes_of_the_bordered_form(E):
     assert rc == -4 and st["stepper_mode"] == 3                                    # DtLessThanMin
     rc, t, v, _, st = e.tran(DFF_TSPAN[0], DFF_TSPAN[1], tran_opts(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-12)))
     assert rc == 0 and t[-1] == DFF_TSPAN[1]
+
+
+def test_subtree_form_with_a_batch_of_samples(E):
+    """The subtree form of the sparse path (sp3_*: per-sample Schur slots, per-sample arrival counter of the top kernel's workgroups)
+    with S > 1: a batch of three coupled 96-tile arrays with their own rail resistances against (a) the level-synchronous kernels on
+    the same batch (`CEDARHIP_SPARSE_NO_SUBTREE=1`) and (b) one-sample solves on the sparse path."""
+    ckt = coupled(96, 1.0)
+    slots = [ckt.slot("rvdd", "r"), ckt.slot("rvss", "r")]
+    rv = np.array([[1.0, 2.5, 0.4], [1.0, 0.7, 3.0]])
+    sv = np.linspace(0.0, 1.2e-7, 25)
+    opts = lambda: tran_opts(abstol=1e-5, reltol=1e-5, saveat=sv, dc=dc_opts(abstol=1e-12))  # noqa: E731
+    e = E(ckt)
+    e.set_samples(3)
+    e.set_params(slots, [rv[0], rv[1]])
+    rc, t, v, xf, st = e.tran(DFF_TSPAN[0], 1.2e-7, opts())
+    assert rc == 0 and st["stepper"] == 1 and e.info()["path"] == 2 and v.shape[2] == 3
+    os.environ["CEDARHIP_SPARSE_NO_SUBTREE"] = "1"
+    try:
+        e2 = E(ckt)
+        e2.set_samples(3)
+        e2.set_params(slots, [rv[0], rv[1]])
+        rc2, t2, v2, _, st2 = e2.tran(DFF_TSPAN[0], 1.2e-7, opts())
+    finally:
+        del os.environ["CEDARHIP_SPARSE_NO_SUBTREE"]
+    assert rc2 == 0 and (st2["naccept"], st2["nreject"]) == (st["naccept"], st["nreject"])
+    assert np.max(np.abs(v - v2)) < 1e-8
+    assert np.max(np.abs(v[-2, :, 1] - v[-2, :, 2])) > 1e-7          # the samples really differ (rail droop)
+    os.environ["CEDARHIP_NO_TEAR"] = "1"
+    try:
+        for s in (1, 2):
+            c1 = coupled(96, (float(rv[0][s]), float(rv[1][s])))
+            rc1, t1, v1, _, st1 = E(c1).tran(DFF_TSPAN[0], 1.2e-7, opts())
+            assert rc1 == 0 and st1["stepper"] == 1
+            assert np.max(np.abs(v1[:, :, 0] - v[:, :, s])) < 2e-3, s   # a batch shares ONE step sequence: the samples agree with their own runs within the tolerance
+    finally:
+        del os.environ["CEDARHIP_NO_TEAR"]
