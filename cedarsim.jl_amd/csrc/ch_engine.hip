@@ -1610,7 +1610,20 @@ struct ch_circuit {
   }
 
   // ------------------------------------------------------------------------------------------
+  // what no solver below should have to defend against: non-finite spans and tolerances, an output grid that is not a grid
+  int check_tran_opts(double t0, double t1, const ch_tran_opts& o) {
+    if (!std::isfinite(t0) || !std::isfinite(t1) || !(t1 > t0)) { set_err("tspan must be finite and increasing"); return CH_ERR_INVALID; }
+    if (!(o.abstol >= 0) || !(o.reltol >= 0) || !std::isfinite(o.abstol) || !std::isfinite(o.reltol) || o.abstol + o.reltol == 0) { set_err("abstol and reltol must be finite, non-negative and not both zero"); return CH_ERR_INVALID; }
+    if (!(o.dtmin >= 0) || !(o.dtmax >= 0) || !(o.dt0 >= 0) || !std::isfinite(o.dtmin) || !std::isfinite(o.dtmax) || !std::isfinite(o.dt0)) { set_err("dtmin, dtmax and dt0 must be finite and non-negative (0 = automatic)"); return CH_ERR_INVALID; }
+    if (o.n_saveat < 0 || (o.n_saveat > 0 && !o.saveat)) { set_err("saveat: n_saveat points announced, none given"); return CH_ERR_INVALID; }
+    for (int i = 0; i < o.n_saveat; ++i)
+      if (!std::isfinite(o.saveat[i]) || (i > 0 && o.saveat[i] < o.saveat[i - 1])) { set_err("saveat must be finite and non-decreasing"); return CH_ERR_INVALID; }
+    if (o.stepper < CH_STEPPER_AUTO || o.stepper > CH_STEPPER_DEVICE) { set_err("stepper must be CH_STEPPER_AUTO, _HOST or _DEVICE"); return CH_ERR_INVALID; }
+    if (o.step_control != CH_STEPS_AUTO && o.step_control != CH_STEPS_SHARED) { set_err("step_control must be CH_STEPS_AUTO or CH_STEPS_SHARED"); return CH_ERR_INVALID; }
+    return CH_OK;
+  }
   int tran_solve(double t0, double t1, const ch_tran_opts& o, ch_result& R) {
+    { const int vrc = check_tran_opts(t0, t1, o); if (vrc != CH_OK) return vrc; }
     if (torn_c && !is_torn && S == 1 && std::getenv("CEDARHIP_NO_TEAR") == nullptr) {
       const char* ev = std::getenv("CEDARHIP_STEPPER");
       int want = o.stepper;

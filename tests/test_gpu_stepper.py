@@ -521,3 +521,25 @@ def test_shared_step_control_on_a_saveat_grid_is_the_run_without_one(E):
     rc2, t2, v2, _, st2 = e.tran(0.0, 7e-7, tran_opts(saveat=sv, stepper="device", **kw))
     assert rc2 == 0 and st2["stepper_mode"] == 2                       # the default on a grid: per-block steps
     assert np.max(np.abs(v2 - v1)) < 0.05 * 5.0                        # the same waveforms within what the tolerance allows at the edges
+
+
+def test_malformed_transient_options_are_refused_not_integrated(E):
+    """`ch_tran` answers CH_ERR_INVALID (-1) with a message — before any solver sees them — for a span that is not finite and
+    increasing, tolerances that are negative / non-finite / both zero, a `saveat` grid that is not finite and non-decreasing, and
+    option codes outside their enums; the circuit stays usable (the torn form and the sparse path share the same check)."""
+    e = E(dff_array(2, observe="q"))
+    ok = dict(abstol=1e-4, reltol=1e-4, dc=dc_opts(abstol=1e-14))
+    bad_spans = [(0.0, 0.0), (1e-7, 0.0), (0.0, float("nan")), (0.0, float("inf")), (float("-inf"), 1e-7)]
+    for t0, t1 in bad_spans:
+        rc = e.tran(t0, t1, tran_opts(**ok))[0]
+        assert rc == -1 and "tspan" in e.ctx.last_error(), (t0, t1, rc, e.ctx.last_error())
+    bad_opts = [dict(abstol=-1e-6), dict(reltol=float("nan")), dict(abstol=0.0, reltol=0.0), dict(abstol=float("inf")), dict(dtmax=-1.0), dict(dt0=float("nan")),
+                dict(saveat=np.array([2e-7, 1e-7])), dict(saveat=np.array([1e-7, np.nan])), dict(stepper=7), dict(step_control=5)]
+    for extra in bad_opts:
+        kw = dict(ok); kw.update(extra)
+        rc = e.tran(0.0, 3e-7, tran_opts(**kw))[0]
+        assert rc == -1 and e.ctx.last_error(), (extra, rc)
+    ec = E(dff_array(8, observe="q", supply_r=1.0))                              # a coupled array: torn form / sparse path
+    assert ec.tran(0.0, 3e-7, tran_opts(saveat=np.array([2e-7, 1e-7]), **ok))[0] == -1
+    rc, t, v, _, st = e.tran(0.0, 3e-7, tran_opts(saveat=np.array([-1e-8, 0.0, 1e-7, 1e-7, 9e-7]), **ok))   # before t0, repeated, beyond t1: a grid all the same
+    assert rc == 0 and len(t) >= 4 and t[-1] <= 3e-7
