@@ -2062,7 +2062,8 @@ int ch_circuit_maps(ch_circuit* c, int32_t* node_unknown, int32_t* node_known, i
 }
 
 static int ch_set_samples_impl(ch_circuit* c, int32_t n) {
-  if (!c || n < 1) return CH_ERR_INVALID;
+  if (!c) return CH_ERR_INVALID;
+  if (n < 1) { c->set_err("ch_set_samples: at least one sample"); return CH_ERR_INVALID; }
   c->S = n;
   for (auto& v : c->slot_val) v.clear();
   c->dirty = true;
@@ -2070,7 +2071,8 @@ static int ch_set_samples_impl(ch_circuit* c, int32_t n) {
   return CH_OK;
 }
 static int ch_set_params_impl(ch_circuit* c, int32_t lo, int32_t hi, int32_t n_slots, const int32_t* ids, const double* values) {
-  if (!c || lo < 0 || hi > c->S || lo >= hi) return CH_ERR_INVALID;
+  if (!c) return CH_ERR_INVALID;
+  if (lo < 0 || hi > c->S || lo >= hi || n_slots < 0 || (n_slots > 0 && (!ids || !values))) { c->set_err("ch_set_params: sample range outside [0, n_samples) or missing arrays"); return CH_ERR_INVALID; }
   for (int i = 0; i < n_slots; ++i) {
     const int id = ids[i];
     if (id < 0 || id >= (int)c->slot_kind.size()) { c->set_err("slot id out of range"); return CH_ERR_INVALID; }
