@@ -195,6 +195,10 @@ __device__ __forceinline__ void eval_linear(const EvalCtx& a, int kind, int d, l
 
 // Evaluate one lane slot of the device-evaluation phase.  slot = (local device << 4) | (first << 3) | direction:
 // compiled Verilog-A devices take one lane per unknown terminal (direction-parallel duals), every other device one lane.
+__device__ __noinline__ void b4_device_call(const B4Col P, double vd, double vg, double vs, double vb, double gmin, double* out) {
+  VA_KEEP_RETURN_ADDRESS;
+  b4_device(P, vd, vg, vs, vb, gmin, out);
+}
 template <bool WIDE>
 __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int slot, const double* xl, int uofs,
                                           const double* kvl, const double* svl, const double* pl, double* stage) {
@@ -229,7 +233,10 @@ __device__ __forceinline__ void eval_slot(const EvalCtx a, int s, int dofs, int 
     // parameters come from the block's LDS copy of its classes' packed columns (staged in the prologue)
     const B4Col P{pl + (size_t)a.dcls_local[d] * B4L_STRIDE};
     double o[40];
-    b4_device(P, v[0], v[1], v[2], v[3], a.gmin, o);
+    // circuits with compiled Verilog-A devices (WIDE) reach the BSIM4 code through a call: inlined, its 6 k instructions and ~460
+    // registers sit in every wide kernel three or four times over, whether the circuit holds a MOSFET or not
+    if (WIDE) b4_device_call(P, v[0], v[1], v[2], v[3], a.gmin, o);
+    else b4_device(P, v[0], v[1], v[2], v[3], a.gmin, o);
 #pragma unroll
     for (int j = 0; j < 40; ++j) st[j] = m * o[j];
     if (WIDE) widen_stamp(st, st_final);
