@@ -317,8 +317,11 @@ int32_t ch_bsim4_param_ignored(const char* name); /* 1 if accepted-and-ignored *
 int ch_ac(ch_circuit*, const ch_dc_opts*, int32_t n_freq, const double* freqs_hz, double* x_ac_out, ch_stats* stats);
 
 /* ---- output-noise PSD.  Replaces: noise!(circ) + PSD(noise, sym, ωs) (src/ac.jl:136-163, 178-186, 286-305).
- * Noise sources built: resistor thermal noise, 4kT/R per instance (src/simpledevices.jl:72-76), T = temp + 273.15.
- * MOSFET noise is not modelled (the BSIM4 noise equations are outside the restated subset).
+ * Noise sources built: resistor thermal noise, 4kT/R per instance (src/simpledevices.jl:72-76), T = temp + 273.15, and the
+ * white / flicker sources of compiled Verilog-A modules (BSIM-CMG: test/ac.jl:155-237).  The noise sources of the hand-written
+ * BSIM4 functor are NOT built (test/inverter_noise.jl:56-124 would pin them, with GF180 cards that are not in the reference tree):
+ * CH_DEV_MOS devices enter the analysis with their small-signal conductances and capacitances only and contribute no noise power of
+ * their own — the PSD of such a circuit is that of its resistors and compiled devices seen through the MOSFETs.
  * out_kind/out_index select the observed unknown like ch_desc.obs_kind/obs_index (0 = node voltage, 1 = branch
  * current); psd_out[n_samples][n_freq] in V²/Hz (A²/Hz), computed with one adjoint solve per frequency. ---- */
 int ch_noise(ch_circuit*, const ch_dc_opts*, int32_t out_kind, int32_t out_index, int32_t n_freq, const double* freqs_hz,
