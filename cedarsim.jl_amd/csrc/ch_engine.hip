@@ -1647,7 +1647,7 @@ struct ch_circuit {
     const double span = t1 - t0;
     if (!(span > 0)) { set_err("tspan must be increasing"); return CH_ERR_INVALID; }
     const double dtmax = o.dtmax > 0 ? o.dtmax : span / 10.0, dtmin = o.dtmin > 0 ? o.dtmin : 1e-15 * span;
-    const int max_steps = o.max_steps > 0 ? o.max_steps : 10000000, nmaxit = o.newton_maxiters > 0 ? o.newton_maxiters : 10;
+    const int max_steps = o.max_steps > 0 ? o.max_steps : 100000 /* Sundials.jl's default maxiters of solve(prob, IDA()) */, nmaxit = o.newton_maxiters > 0 ? o.newton_maxiters : 10;
     const int n_obs = R.n_obs;
 
     // ring bookkeeping: order[] lists slots newest-first

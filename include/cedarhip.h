@@ -190,7 +190,8 @@ typedef struct ch_tran_opts {
   double dtmin;      /* default 1e-18*(t1-t0)... 0 = auto */
   double dtmax;      /* 0 = auto ((t1-t0)/10) */
   double dt0;        /* initial step, 0 = auto */
-  int32_t max_steps; /* 0 = 10 000 000 */
+  int32_t max_steps; /* accepted steps before CH_ERR_MAXSTEPS (ReturnCode.MaxIters); 0 = 100 000, the default maxiters of solve(prob, IDA()) in Sundials.jl (the
+                        reference passes none, src/sweeps.jl:456).  A transient that creeps (Newton failing whenever the step grows) ends there. */
   int32_t newton_maxiters; /* default 10 */
   int32_t n_saveat;        /* 0: save every accepted step (ONE step sequence and time vector for the whole circuit / batch) */
   const double* saveat;    /* [n_saveat] increasing times to save (dense output by interpolation).  With a saveat grid the samples of a batch,

@@ -461,7 +461,7 @@ static int tran_solve(Circuit& c, double t0, double t1, const ch_tran_opts& o, R
   const double span = t1 - t0;
   const double dtmax = o.dtmax > 0 ? o.dtmax : span / 10.0;
   const double dtmin = o.dtmin > 0 ? o.dtmin : 1e-15 * span;
-  const int max_steps = o.max_steps > 0 ? o.max_steps : 10000000;
+  const int max_steps = o.max_steps > 0 ? o.max_steps : 100000;   // Sundials.jl's default maxiters of solve(prob, IDA()) (src/sweeps.jl:456 passes none)
   const int nmaxit = o.newton_maxiters > 0 ? o.newton_maxiters : 10;
 
   // ---- initialisation: CedarDCOp, then the problem's own mode at t0 ----
