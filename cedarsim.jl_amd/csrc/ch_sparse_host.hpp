@@ -146,18 +146,84 @@ inline bool max_transversal(int n, const std::vector<int>& rowptr, const std::ve
   return true;
 }
 
+// Pivot ROWS from an actual elimination of the given values (what KLU's first factorisation does; the GPU refactorisation then
+// reuses the sequence and never searches).  Columns are taken in the fill-reducing order `order`; at step k the pivot of column
+// order[k] is the matched row (`row_of_col`, the zero-free-diagonal matching: keeps the pattern the ordering was made for) when its
+// current value is at least `tol` of the largest candidate in the column — KLU's rule, tol = 1e-3 — and the largest candidate
+// otherwise.  "Current value": after the updates of the earlier pivots, which is where a matching alone goes wrong — an entry that
+// is large in A can cancel to exactly zero (ideal sources and controlled sources in MNA do that), and a static sequence built on it
+// divides by zero whatever the refactorisation does afterwards.  Right-looking on sparse rows; returns false when a column has no
+// non-zero candidate left (numerically singular).
+inline bool numeric_pivot_rows(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& aval,
+                               const std::vector<int>& order, const std::vector<int>& row_of_col, std::vector<int>& prow, double tol = 1e-3) {
+  std::vector<std::map<int, double>> R(n);
+  std::vector<std::vector<int>> col_rows(n);          // rows that hold (or held) an entry in the column: filtered when used
+  std::vector<double> rowmax(n, 0.0);
+  for (int i = 0; i < n; ++i) for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+    auto it = R[i].find(colidx[p]);
+    if (it == R[i].end()) { R[i][colidx[p]] = aval[p]; col_rows[colidx[p]].push_back(i); } else it->second += aval[p];
+    rowmax[i] = std::max(rowmax[i], std::fabs(aval[p]));
+  }
+  std::vector<char> done(n, 0);
+  prow.assign(n, -1);
+  for (int k = 0; k < n; ++k) {
+    const int c = order[k];
+    std::vector<int> cand;
+    double amax = 0.0;
+    std::sort(col_rows[c].begin(), col_rows[c].end());
+    col_rows[c].erase(std::unique(col_rows[c].begin(), col_rows[c].end()), col_rows[c].end());
+    for (int i : col_rows[c]) {
+      if (done[i]) continue;
+      auto it = R[i].find(c);
+      if (it == R[i].end()) continue;
+      cand.push_back(i);
+      const double v = std::fabs(it->second);
+      if (v > 1e-13 * rowmax[i]) amax = std::max(amax, v);     // below that: what a cancellation left behind, never a pivot
+    }
+    if (!(amax > 0.0) || !(amax < 1e300)) return false;
+    int pick = -1;
+    { const int m = row_of_col[c];
+      if (m >= 0 && !done[m]) { auto it = R[m].find(c); if (it != R[m].end() && std::fabs(it->second) >= tol * amax && std::fabs(it->second) > 1e-13 * rowmax[m]) pick = m; } }
+    if (pick < 0) for (int i : cand) { const double v = std::fabs(R[i][c]); if (v == amax) { pick = i; break; } }   // the largest, lowest row on ties
+    if (pick < 0) return false;
+    prow[k] = pick; done[pick] = 1;
+    const std::map<int, double>& pr = R[pick];
+    const double pv = pr.at(c);
+    for (int i : cand) {
+      if (i == pick) continue;
+      std::map<int, double>& ri = R[i];
+      const double l = ri[c] / pv;
+      ri.erase(c);
+      if (l == 0.0) continue;
+      for (const auto& e : pr) {
+        if (e.first == c) continue;
+        auto it = ri.find(e.first);
+        if (it == ri.end()) { ri[e.first] = -l * e.second; col_rows[e.first].push_back(i); } else it->second -= l * e.second;
+      }
+    }
+  }
+  return true;
+}
+
 // Build the plan.  aval: numeric values of A (same order as colidx) used to pick significant entries.
 inline int sparse_analyse(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, const std::vector<double>& aval, SparsePlan& P) {
   P.n = n; P.rowptr = rowptr; P.colidx = colidx;
   const int nnz = (int)colidx.size();
-  // 1. zero-free diagonal on significant entries (|a| >= 1e-3 of the row maximum), fall back to any structural entry
+  // 1. zero-free diagonal on entries that are LARGE in their row: the pivots are static (the GPU refactorisation never searches), so
+  //    the matching is all the pivoting there is.  A bottleneck matching by thresholds: the largest theta of the ladder for which a
+  //    perfect matching exists on the entries with |a| >= theta * (row maximum) — every pivot then starts at least that large
+  //    relative to its row (with the single 1e-3 rung of rounds 1-3, three random RLC / controlled-source networks of 20-70 nodes in
+  //    a hundred lost a transient to element growth: scripts/extended_fuzz.py).  Falls back to any structural entry.
   std::vector<char> usable(nnz, 0);
-  for (int i = 0; i < n; ++i) {
-    double mx = 0; for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) mx = std::max(mx, std::fabs(aval[p]));
-    for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) usable[p] = (mx > 0 && std::fabs(aval[p]) >= 1e-3 * mx);
-  }
+  std::vector<double> rowmax(n, 0.0);
+  for (int i = 0; i < n; ++i) for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) rowmax[i] = std::max(rowmax[i], std::fabs(aval[p]));
   std::vector<int> row_of_col;
-  if (!max_transversal(n, rowptr, colidx, usable, row_of_col)) {
+  bool matched = false;
+  for (double theta : {0.9, 0.5, 0.2, 0.05, 0.01, 1e-3}) {
+    for (int i = 0; i < n; ++i) for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) usable[p] = (rowmax[i] > 0 && std::fabs(aval[p]) >= theta * rowmax[i]);
+    if (max_transversal(n, rowptr, colidx, usable, row_of_col)) { matched = true; break; }
+  }
+  if (!matched) {
     std::fill(usable.begin(), usable.end(), 1);
     if (!max_transversal(n, rowptr, colidx, usable, row_of_col)) return CH_ERR_SINGULAR;
   }
@@ -184,6 +250,9 @@ inline int sparse_analyse(int n, const std::vector<int>& rowptr, const std::vect
   P.prow.resize(n);
   std::vector<int> pos_of_col(n);
   for (int k = 0; k < n; ++k) { pos_of_col[order[k]] = k; P.prow[k] = row_of_col[order[k]]; }
+  // 2b. the pivot rows from an elimination of these values (the matching is the starting point and wins wherever it is sound)
+  { std::vector<int> pr;
+    if (numeric_pivot_rows(n, rowptr, colidx, aval, order, row_of_col, pr)) P.prow = pr; }   // numerically singular: keep the matching, the refactorisation will say so
   // 3. symbolic row-wise factorisation in pivot space
   std::vector<std::vector<int>> rowpat(n);  // sorted pivot-space columns of row k of L+U
   for (int k = 0; k < n; ++k) {

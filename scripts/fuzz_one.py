@@ -24,3 +24,13 @@ print("info", e.info(), flush=True)
 t0 = time.time()
 rce, te, ve, _, ste = e.tran(0.0, 1e-6, tran_opts(abstol=1e-9, reltol=1e-6, saveat=sv, dc=dc_opts(abstol=1e-12, tran_mode=1), stepper=stp, max_steps=max_steps))
 print(stp, "rc", rce, "accepted", ste["naccept"], "rejected", ste["nreject"], "convfail", ste["nnonlinconvfail"], "rows", len(te), "stepper", ste["stepper"], ste["stepper_mode"], "%.2f s" % (time.time() - t0), e.ctx.last_error(), flush=True)
+print("info after", {k: v for k, v in e.info().items() if k in ("path", "max_component", "nnz_jac", "nnz_lu", "n_components")}, flush=True)
+rcd, xd, std_, _ = e.dc(dc_opts(abstol=1e-12, tran_mode=1))
+print("dc alone rc", rcd, e.ctx.last_error(), flush=True)
+vo2 = vo if vo.ndim == 2 else vo[:, :, 0]
+if rce == 0 and rco == 0:
+    d = np.abs(ve[:, :, 0] - vo2)
+    print("max |engine| %.3e  max |oracle| %.3e  max diff %.3e at obs %d, time index %d" % (np.abs(ve).max(), np.abs(vo2).max(), d.max(), np.unravel_index(d.argmax(), d.shape)[0], np.unravel_index(d.argmax(), d.shape)[1]))
+    k = np.unravel_index(d.argmax(), d.shape)[0]
+    print("engine row", ve[k, :, 0]); print("oracle row", vo2[k, :])
+print("devices:", [(c.dev_names[i], c.dev_kind[i]) for i in range(len(c.dev_kind))][:60])

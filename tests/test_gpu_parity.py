@@ -852,3 +852,27 @@ def test_sweep_with_dc_warm_start_gives_the_same_answers():
     for x, y in zip(a, b):
         assert y.retcode == "Success" and np.max(np.abs(np.array(x["q"]) - np.array(y["q"]))) < 5e-4
         assert np.max(np.abs(np.array(y["q"]) - np.array(DFF_CHECK_Q))) < 1e-3
+
+
+def test_large_random_networks_on_the_sparse_path_match_oracle(E, O):
+    """Seeds of scripts/extended_fuzz.py (random RLC / controlled-source / MOSFET networks of up to 70 nodes: ONE block of 66–109
+    unknowns, sparse path) on which the static pivot sequence of rounds 1–3 met exact zero pivots: the transient gave up with
+    DtLessThanMin on its first step (20065, 20095, 20110) or the operating point did not converge (20981), while the oracle's dense
+    LU had no trouble.  The pivot rows now come from an elimination of the actual values (ch_sparse_host.hpp numeric_pivot_rows)."""
+    sv = np.array([1e-7, 2e-7, 3.5e-7, 5.5e-7, 6e-7, 1e-6])
+    for seed in (20065, 20095, 20110, 20981):
+        rng = np.random.default_rng(seed)
+        c = _random_circuit(rng, int(rng.integers(3, 70)), with_mos=seed % 2 == 0)
+        c.observe_all_nodes()
+        e, o = E(c), O(c)
+        rc_o, x_o, _ = o.dc(dc_opts(abstol=1e-12))
+        rc, x, status, st = e.dc(dc_opts(abstol=1e-12))
+        assert rc_o == 0 and rc == 0 and e.info()["path"] == 2, (seed, rc_o, rc, e.ctx.last_error())
+        known = ~np.isnan(x[0])
+        assert np.allclose(x[0][known], x_o[known], rtol=1e-6, atol=1e-9), (seed, np.abs(x[0][known] - x_o[known]).max())
+        opts = lambda: tran_opts(abstol=1e-9, reltol=1e-6, saveat=sv, dc=dc_opts(abstol=1e-12, tran_mode=1))  # noqa: E731
+        rce, te, ve, _, _ = e.tran(0.0, 1e-6, opts())
+        rco, to, vo, _, _ = o.tran(0.0, 1e-6, opts())
+        vo = vo if vo.ndim == 2 else vo[:, :, 0]
+        assert rce == 0 and rco == 0, (seed, rce, rco, e.ctx.last_error())
+        assert np.abs(ve[:, :, 0] - vo).max() < 1e-4 * max(1.0, np.abs(vo).max()), (seed, np.abs(ve[:, :, 0] - vo).max())

@@ -44,6 +44,23 @@ def test_subtree_form_of_the_sparse_analysis_replays_exactly(tmp_path):
     assert "60 plans replayed" in r.stdout and " 0 failures" in r.stdout
 
 
+def test_static_pivot_sequence_survives_cancellation_in_mna_matrices(tmp_path):
+    """The GPU refactorisation never searches for a pivot, so the sequence the host analysis hands it has to be sound for the values
+    it was made from.  Two MNA Jacobians of a random RLC / controlled-source network (the oracle's, written by
+    tests/golden/make_mna_jacobian.py: seed 20095 of scripts/extended_fuzz.py at alpha0 = 0 and 1e12): a matching on entries that are
+    large in their rows — rounds 1-3 — divides by an exact zero after a few eliminations on both; the sequence taken from an actual
+    elimination (ch_sparse_host.hpp numeric_pivot_rows, KLU's rule) solves them to 1e-8 of the right-hand side."""
+    import subprocess
+    exe = str(tmp_path / "replay")
+    r = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-D_GLIBCXX_ASSERTIONS",
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cedarsim.jl_amd", "csrc"),
+                        os.path.join(ROOT, "tests", "host_matrix_replay.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = os.path.join(ROOT, "tests", "golden")
+    r = subprocess.run([exe, os.path.join(g, "mna_jacobian_seed20095_dc.txt"), os.path.join(g, "mna_jacobian_seed20095_tran.txt")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "0 bad" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
 def test_return_address_scanner_flags_the_pattern(tmp_path):
     """scripts/check_return_address.py on two hand-written device functions: one whose long-branch expansion writes s[30:31]
     without a saved copy (the code-generator defect worked around in csrc/va_rt.hpp), one that saved the pair first."""
