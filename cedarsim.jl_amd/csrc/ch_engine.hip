@@ -2303,6 +2303,15 @@ static int ch_ac_impl(ch_circuit* c, const ch_dc_opts* o, int32_t n_freq, const 
   a.bmeta = c->ac_bmeta(); a.G = c->d_dumpG.p; a.C = c->d_dumpC.p; a.b = c->d_dumpF.p; a.ds = ds; a.S = S; a.n_unk = A.n_unk; a.n_freq = n_freq; a.n_comp = c->ac_ncomp();
   if (!a.bmeta) return CH_ERR_DEVICE;
   a.omega = c->d_omega.p; a.x_out = c->d_xac.p; a.noise = 0; a.fail = c->d_acfail.p;
+  if (std::getenv("CEDARHIP_DEBUG_AC") && ds <= 8 && nblk == 1) {   // diagnostic: the linearisation the complex solves start from
+    std::vector<double> hg((size_t)ds * ds), hc((size_t)ds * ds), hb(ds);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)hipMemcpy(hg.data(), c->d_dumpG.p, hg.size() * sizeof(double), hipMemcpyDeviceToHost); (void)hipMemcpy(hc.data(), c->d_dumpC.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hb.data(), c->d_dumpF.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost);
+    { std::vector<double> hx(A.n_unk); (void)hipMemcpy(hx.data(), c->d_X.p, hx.size() * sizeof(double), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "[ac] state:"); for (double v : hx) std::fprintf(stderr, " %.12e", v); std::fprintf(stderr, "\n"); }
+    for (int i = 0; i < ds; ++i) { std::fprintf(stderr, "[ac] G row %d:", i); for (int j = 0; j < ds; ++j) std::fprintf(stderr, " %.9e", hg[(size_t)i * ds + j]); std::fprintf(stderr, " | C:"); for (int j = 0; j < ds; ++j) std::fprintf(stderr, " %.9e", hc[(size_t)i * ds + j]); std::fprintf(stderr, " | b %.9e\n", hb[i]); }
+  }
   rc = launch_ac(c, a, n_freq, nblk, ds);
   if (rc != CH_OK) return rc;
   std::vector<double> xs(nx);
