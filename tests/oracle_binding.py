@@ -111,7 +111,8 @@ class Oracle:
             nobs = len(self.circuit.obs)
             t = np.ctypeslib.as_array(self.L.oracle_result_times(r), (nt,)).copy() if nt else np.zeros(0)
             v = np.ctypeslib.as_array(self.L.oracle_result_values(r), (nobs, nt)).copy() if nt and nobs else np.zeros((nobs, nt))
-            xf = np.ctypeslib.as_array(self.L.oracle_result_final_state(r), (self.n,)).copy()
+            pf = self.L.oracle_result_final_state(r)   # NULL when the operating point already failed: no state to report
+            xf = np.ctypeslib.as_array(pf, (self.n,)).copy() if pf else np.full(self.n, np.nan)
             st = ChStats()
             self.L.oracle_result_stats(r, C.byref(st))
             return self.L.oracle_result_status(r), t, v, xf, st.asdict()
