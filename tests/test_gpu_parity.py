@@ -587,12 +587,14 @@ def test_large_batch_uses_the_device_side_reduction(E):
     assert np.abs(v2[0] - v[0][:, :2]).max() < 1e-9
 
 
-def _random_circuit(rng, n_nodes, with_mos):
+def _random_circuit(rng, n_nodes, with_mos, c=None, prefix=""):
     """Connected random network: a resistive spanning tree to ground keeps every node's DC value defined; on top of it
-    random R, C, L, I, grounded and floating V sources (incl. 0 V ammeters), VCVS / VCCS and, optionally, MOSFETs."""
+    random R, C, L, I, grounded and floating V sources (incl. 0 V ammeters), VCVS / VCCS and, optionally, MOSFETs.
+    `c` + `prefix`: add the network to an existing circuit under prefixed names (several networks that share only ground
+    = several independent Jacobian blocks)."""
     from cedarsim_jl_amd.workloads import gf180_models
-    c = Circuit(gmin=1e-12)
-    names = ["n%d" % i for i in range(1, n_nodes + 1)]
+    c = Circuit(gmin=1e-12) if c is None else c
+    names = ["%sn%d" % (prefix, i) for i in range(1, n_nodes + 1)]
     mi = {}
     if with_mos:
         m = gf180_models()
@@ -602,7 +604,7 @@ def _random_circuit(rng, n_nodes, with_mos):
     def nm(p):
         nonlocal k
         k += 1
-        return "%s%d" % (p, k)
+        return "%s%s%d" % (prefix, p, k)
 
     def pick():
         return names[rng.integers(n_nodes)] if rng.random() > 0.15 else 0
