@@ -430,7 +430,8 @@ class CircuitSweep:
         if names and len(pts) > 1 and all(set(p) == set(names) for p in pts):
             distinct = {k: list(dict.fromkeys(p[k] for p in pts)) for k in names}
             n_check = min(4, len(pts) - 1)
-            cost = 1 + sum(min(len(v) - 1, 2) if all(numeric(x) for x in v) else len(v) - 1 for v in distinct.values()) + n_check
+            fitted = [k for k in names if len(distinct[k]) > 4 and all(numeric(x) for x in distinct[k])]   # variables whose map is fitted, not looked up
+            cost = 1 + sum(min(len(v) - 1, 2) if all(numeric(x) for x in v) else len(v) - 1 for v in distinct.values()) + n_check + 2 * len(fitted)
             if cost < len(pts):
                 table = self._learn_table(pts, names, distinct, v0, flat_of, differs, close, numeric)
                 if table is not None:
@@ -438,6 +439,16 @@ class CircuitSweep:
                     far = max(range(1, len(pts)), key=lambda r: sum(pts[r][k] != pts[0][k] for k in names))
                     rng = np.random.default_rng(len(pts))
                     picks = {far, len(pts) - 1} | {int(r) for r in rng.integers(1, len(pts), size=max(0, n_check - 2))}
+                    # ... and, for every variable whose map was FITTED from three values, the points that hold its smallest and its
+                    # largest value: a clipped or saturating entry (max(x, lower bound), a model card's limits) is affine on the
+                    # three fitted values and wrong beyond the kink (scripts/extended_fuzz_sweepmap.py, 2 of 1 500 random builders)
+                    # Among the points that hold such an extreme, the one with the most OTHER variables away from the base point: an
+                    # entry that follows one variable only while another is beyond a threshold shows there and nowhere on the axes.
+                    away = lambda r: sum(pts[r][j] != pts[0][j] for j in names)  # noqa: E731
+                    for k in fitted:
+                        for ext in (min(p[k] for p in pts), max(p[k] for p in pts)):
+                            picks.add(max((r for r in range(len(pts)) if pts[r][k] == ext), key=lambda r: (away(r), r)))
+                    picks.discard(0)
                     for r in sorted(picks):
                         if not close(flat_of(pts[r]), table[r]):
                             table = None   # e.g. an entry that depends on two swept variables

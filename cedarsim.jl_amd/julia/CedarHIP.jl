@@ -558,8 +558,8 @@ end
 # lists them).  Which table entries a name moves is LEARNED, not assumed: the stamp table of the base point is diffed against the
 # tables of a few single-variable variations — one per distinct value when a variable has at most four, otherwise two that fix an
 # identity / proportional / affine map plus a third that checks it — and the assembled per-point table is validated against full
-# extractions of the far corner and of seeded random points (an entry that answers to two variables is invisible from single-axis
-# variations).  Any failed check falls back to one extraction per point.  Same algorithm as cedarsim.jl_amd/api.py CircuitSweep._batch,
+# extractions of the far corner, of seeded random points and of the points that hold the extremes of every fitted variable (an entry
+# that answers to two variables, or is clipped beyond the fitted values, is invisible from single-axis variations).  Any failed check falls back to one extraction per point.  Same algorithm as cedarsim.jl_amd/api.py CircuitSweep._batch,
 # which the CPU tests cover (tests/test_netlist_and_sweeps.py).
 "Every sweepable entry of a stamp table as one vector, with the engine slot (kind, a, b) of each position (cedarhip.h CH_SLOT_*)."
 function flat_table(pass::StampPass)
@@ -601,12 +601,20 @@ function sweep_table(circuit, iterator)
     if n > 1 && all(p -> Set(keys(p)) == Set(names), points)
         distinct = Dict(k => unique(p[k] for p in points) for k in names)
         ncheck = min(4, n - 1)
-        cost = 1 + sum(min(length(distinct[k]) - 1, 2) for k in names) + ncheck
+        fitted = [k for k in names if length(distinct[k]) > 4 && all(v -> v isa Real, distinct[k])]    # maps that are fitted, not looked up
+        cost = 1 + sum(min(length(distinct[k]) - 1, 2) for k in names) + ncheck + 2 * length(fitted)
         cost < n && (table = learn_table(points, names, distinct, v0, flat_of))
         if table !== nothing
-            far = argmax([count(k -> points[r][k] != points[1][k], names) for r in 1:n])
-            picks = unique(vcat(far, n, [2 + (7919 * q) % (n - 1) for q in 1:max(0, ncheck - 2)]))     # far corner, last point, seeded others
-            for r in picks
+            away(r) = count(k -> points[r][k] != points[1][k], names)
+            far = argmax([away(r) for r in 1:n])
+            picks = vcat(far, n, [2 + (7919 * q) % (n - 1) for q in 1:max(0, ncheck - 2)])             # far corner, last point, seeded others
+            # for every fitted variable the points that hold its smallest and largest value, with the most OTHER variables away from the
+            # base point: a clipped entry (affine on the three fitted values, wrong beyond the kink) or one gated by another variable
+            for k in fitted, ext in (minimum(distinct[k]), maximum(distinct[k]))
+                cand = [r for r in 1:n if points[r][k] == ext]
+                push!(picks, cand[argmax([(away(r), r) for r in cand])])
+            end
+            for r in unique(picks)
                 r == 1 && continue
                 all(closev.(flat_of(points[r]), table[r, :])) || (table = nothing; break)   # e.g. an entry that depends on two swept variables
             end

@@ -175,7 +175,8 @@ def test_solution_call_interpolates_with_pchip():
 def test_sweep_batch_learns_the_parameter_map_from_few_builds():
     """CircuitSweep._batch (the host half of `remake(prob, p=sim)` over a sweep, src/sweeps.jl:471-482): a product sweep whose
     variables act on disjoint table entries is assembled from a handful of builds (the base point, two per axis for the
-    identity / affine map, up to four validation points: at most 9 for the reference's 400-point sweep, test/sweep.jl:326-340),
+    identity / affine map, up to four validation points plus the two extremes of every fitted variable: at most 13 for the
+    reference's 400-point sweep, test/sweep.jl:326-340),
     a sweep with a coupled entry falls back to one build per point, and both give the per-point tables exactly."""
     import numpy as np
     from cedarsim_jl_amd import Circuit, CircuitSweep, ProductSweep, TandemSweep, frange
@@ -191,7 +192,7 @@ def test_sweep_batch_learns_the_parameter_map_from_few_builds():
 
     cs = CircuitSweep(two_resistor, ProductSweep(R1=frange(100.0, 100.0, 2000.0), R2=frange(100.0, 100.0, 2000.0)))
     base, ids, vals = cs._batch(0, 400)
-    assert count["n"] <= 9 and vals.shape == (2, 400) and len(base.slots) == 2 and cs.setup["circuit_builds"] == count["n"]
+    assert count["n"] <= 13 and vals.shape == (2, 400) and len(base.slots) == 2 and cs.setup["circuit_builds"] == count["n"]
     r1 = [p["R1"] for p in cs]
     r2 = [p["R2"] for p in cs]
     by_slot = {s[1]: vals[i] for i, s in enumerate(base.slots)}
@@ -243,6 +244,36 @@ def test_sweep_batch_is_validated_against_full_builds():
     assert np.array_equal(vals[0], [1.0 / p["g"] for p in cs]) and cs.setup["circuit_builds"] < 72
 
 
+def test_sweep_batch_catches_clipped_and_gated_entries():
+    """What scripts/extended_fuzz_sweepmap.py found (2 of 1 500 random builders, silently wrong values): an entry that is affine on the
+    three fitted values of its variable and clipped beyond them, and an entry that follows one variable only while another is above a
+    threshold.  The validation now includes, for every fitted variable, the points that hold its extremes with the most other
+    variables away from the base point."""
+    from cedarsim_jl_amd import Circuit, CircuitSweep
+
+    def build(a=2.2, b=2.9):
+        c = Circuit()
+        c.V("V", "vcc", 0, dc=1.0)
+        c.R("R1", "vcc", "mid", a)
+        c.R("R2", "mid", 0, max(b, 2.0) * 1.8)          # clipped below b = 2
+        c.R("R3", "mid", 0, b if a > 2.0 else 50.0)      # gated by the other variable
+        return c
+    rng = np.random.default_rng(36)
+    npts = 32
+    cs = CircuitSweep(build, TandemSweep(a=[float(x) for x in rng.uniform(0.5, 4.0, npts)], b=[float(x) for x in rng.uniform(0.5, 4.0, npts)]))
+    base, ids, vals = cs._batch(0, npts)
+    for r in range(npts):
+        c = build(**cs.points[r])
+        for i, sl in enumerate(base.slots):
+            assert vals[i][r] == c.dev_par[sl[1]][sl[2]], (r, sl, cs.setup["how"])
+    cs = CircuitSweep(build, ProductSweep(a=[0.855, 1.504, 1.971, 1.894, 3.994, 1.111], b=[1.778, 3.762, 3.168, 2.994, 1.996]))
+    base, ids, vals = cs._batch(0, 30)
+    for r in range(30):
+        c = build(**cs.points[r])
+        for i, sl in enumerate(base.slots):
+            assert vals[i][r] == c.dev_par[sl[1]][sl[2]], (r, sl, cs.setup["how"])
+
+
 def test_monte_carlo_tandem_sweep_needs_a_handful_of_builds():
     """process-variation samples enter as an explicit TandemSweep (src/sweeps.jl:278-290) with as many
     distinct values as points.  The name -> table-entry map is learned from three builds per variable (identity /
@@ -254,7 +285,7 @@ def test_monte_carlo_tandem_sweep_needs_a_handful_of_builds():
     build, names = dff_mc_builder()
     cs = CircuitSweep(build, mc_tandem_sweep(S))
     base, ids, vals = cs._batch(0, S)
-    assert cs.setup["circuit_builds"] <= 1 + 2 * len(names) + 4 and vals.shape[1] == S and cs.setup["how"].startswith("learned")
+    assert cs.setup["circuit_builds"] <= 1 + 4 * len(names) + 4 and vals.shape[1] == S and cs.setup["how"].startswith("learned")
     assert len(base.slots) == 6 + 2 * 30   # six card entries, W and L of the thirty MOSFETs
     for r in (1, 17, 200, S - 1):   # against the per-point build
         c = build(**cs.points[r])
