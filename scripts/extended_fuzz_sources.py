@@ -1,0 +1,119 @@
+"""Extended differential fuzz of the source waveforms and the break-point policy (not part of the suite): two to four sources with random
+PWL (corners AND jumps), PULSE (zero and non-zero edges, periodic) and SIN (delay, damping, cycle limit) waveforms drive RC / RLC / one
+MOSFET stage loads; both step controllers, with and without a saveat grid, against the oracle.  The policy lives in three places
+(oracle.cpp, ch_engine.hip tran_solve, ch_persist.hpp): this is the test that they are one policy.
+usage: python scripts/extended_fuzz_sources.py [first_seed] [n_seeds] [seconds]"""
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+from cedarsim_jl_amd import dc_opts, tran_opts  # noqa: E402
+from cedarsim_jl_amd.circuit import PULSE, PWL, SIN, Circuit  # noqa: E402
+from cedarsim_jl_amd.engine import EngineCircuit  # noqa: E402
+from cedarsim_jl_amd.workloads import gf180_models  # noqa: E402
+from oracle_binding import Oracle  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 300.0
+T1 = 1e-6
+t_start = time.time()
+fails, done, skipped, modes = [], 0, 0, {}
+
+
+def wave(rng):
+    k = rng.integers(0, 3)
+    if k == 0:
+        n = int(rng.integers(2, 7))
+        ts = np.sort(rng.uniform(0.0, T1, n))
+        if rng.random() < 0.5 and n >= 3:       # a jump: a repeated time
+            j = int(rng.integers(1, n - 1)); ts[j + 1] = ts[j]
+        ys = rng.uniform(-1.0, 3.0, n)
+        return float(ys[0]), PWL(np.concatenate(([0.0], ts)).tolist(), np.concatenate(([ys[0]], ys)).tolist())
+    if k == 1:
+        v1, v2 = float(rng.uniform(-1, 1)), float(rng.uniform(1, 3))
+        tr = 0.0 if rng.random() < 0.3 else float(10 ** rng.uniform(-10, -8))
+        tf = 0.0 if rng.random() < 0.3 else float(10 ** rng.uniform(-10, -8))
+        pw = float(rng.uniform(2e-8, 2e-7))
+        per = float(pw + tr + tf + rng.uniform(2e-8, 3e-7)) if rng.random() < 0.7 else float("inf")
+        return v1, PULSE(v1, v2, td=float(rng.uniform(0, 2e-7)), tr=tr, tf=tf, pw=pw, period=per)
+    vo, va = float(rng.uniform(-1, 2)), float(rng.uniform(0.2, 2))
+    freq = float(10 ** rng.uniform(6.3, 7.5))
+    td = 0.0 if rng.random() < 0.4 else float(rng.uniform(0, 3e-7))
+    theta = 0.0 if rng.random() < 0.5 else float(rng.uniform(1e5, 5e6))
+    nc = float("inf") if rng.random() < 0.6 else float(rng.integers(1, 5))
+    w = SIN(vo, va, freq, td=td, theta=theta, phase=float(rng.uniform(0, 360)) if rng.random() < 0.3 else 0.0, ncycles=nc)
+    return None, w
+
+
+for seed in range(first, first + n_seeds):
+    if time.time() - t_start > budget:
+        break
+    if (seed - first) % 100 == 0:
+        print("progress: seed %d, %d compared, %d failures, %.0f s, %s" % (seed, done, len(fails), time.time() - t_start, modes), flush=True)
+    rng = np.random.default_rng(seed)
+    c = Circuit(gmin=1e-12)
+    nsrc = int(rng.integers(2, 5))
+    share = rng.random() < 0.5        # sources into ONE load (one block) or each its own load (independent blocks)
+    if rng.random() < 0.3:
+        m = gf180_models(); mn = c.add_model(*m["nfet_06v0"])
+    else:
+        mn = None
+    for i in range(nsrc):
+        dc0, w = wave(rng)
+        kw = {"tran": w} if dc0 is None else {"dc": dc0, "tran": w}
+        if dc0 is None:
+            kw["dc"] = 0.0
+        c.V("v%d" % i, "s%d" % i, 0, **kw)
+        out = "o" if share else "o%d" % i
+        c.R("r%d" % i, "s%d" % i, "m%d" % i, float(10 ** rng.uniform(2, 4)))
+        if rng.random() < 0.3:
+            c.L("l%d" % i, "m%d" % i, out, float(10 ** rng.uniform(-7, -5.5)))
+        else:
+            c.R("rr%d" % i, "m%d" % i, out, float(10 ** rng.uniform(1, 3)))
+        c.C("cm%d" % i, "m%d" % i, 0, float(10 ** rng.uniform(-13, -11)))
+        if not share or i == 0:
+            c.C("co%d" % i, out, 0, float(10 ** rng.uniform(-13, -11)))
+            c.R("ro%d" % i, out, 0, float(10 ** rng.uniform(3, 5)))
+            if mn is not None and rng.random() < 0.5:
+                c.M("mq%d" % i, "d%d" % i, out, 0, 0, mn, 2e-6, 6e-7)
+                c.R("rd%d" % i, "s0", "d%d" % i, 2e4)
+    c.observe_all_nodes()
+    sv = np.sort(rng.uniform(0.0, T1, 12))
+    try:
+        o, e = Oracle(c), EngineCircuit(c)
+        for key, grid in (("grid", sv), ("all", None)):
+            mk = lambda stp: tran_opts(abstol=1e-8, reltol=1e-6, saveat=grid, dc=dc_opts(abstol=1e-12), stepper=stp)  # noqa: E731
+            rco, to, vo, _, sto = o.tran(0.0, T1, mk("auto"))
+            vo = vo if vo.ndim == 2 else vo[:, :, 0]
+            if rco != 0:
+                skipped += 1
+                continue
+            for stp in ("host", "device"):
+                rce, te, ve, _, ste = e.tran(0.0, T1, mk(stp))
+                if stp == "device" and rce == -6:
+                    continue
+                modes[(stp, key, ste["stepper_mode"])] = modes.get((stp, key, ste["stepper_mode"]), 0) + 1
+                if rce != 0:
+                    fails.append((seed, "tran rc", stp, key, rce, e.ctx.last_error()[:60]))
+                    continue
+                if key == "grid":
+                    err = float(np.abs(ve[:, :, 0] - vo).max())
+                    tol = 2e-4
+                else:
+                    if stp == "host" and (len(te) != len(to) or ste["naccept"] != sto["naccept"]):
+                        pass   # the step sequences may differ by rounding; compare by interpolation below
+                    err = max(float(np.abs(np.interp(to, te, ve[k, :, 0]) - vo[k]).max()) for k in range(vo.shape[0]))
+                    tol = 2e-2    # linear interpolation between the engine's own steps across corners
+                if not err < tol * max(1.0, float(np.abs(vo).max())):
+                    fails.append((seed, "tran v", stp, key, err, float(np.abs(vo).max()), ste["naccept"], sto["naccept"]))
+        done += 1
+    except Exception as ex:  # noqa: BLE001
+        fails.append((seed, "raised", type(ex).__name__, str(ex)[:160]))
+for fl in fails:
+    print("FAIL", fl)
+print("seeds %d..%d: %d compared, %d skipped, %d failures, %.0f s, %s" % (first, seed, done, skipped, len(fails), time.time() - t_start, modes))
+sys.exit(1 if fails else 0)
