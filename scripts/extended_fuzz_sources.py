@@ -104,10 +104,14 @@ for seed in range(first, first + n_seeds):
                     err = float(np.abs(ve[:, :, 0] - vo).max())
                     tol = 2e-4
                 else:
-                    if stp == "host" and (len(te) != len(to) or ste["naccept"] != sto["naccept"]):
-                        pass   # the step sequences may differ by rounding; compare by interpolation below
-                    err = max(float(np.abs(np.interp(to, te, ve[k, :, 0]) - vo[k]).max()) for k in range(vo.shape[0]))
-                    tol = 2e-2    # linear interpolation between the engine's own steps across corners
+                    if len(te) != len(to) or not np.allclose(te, to, rtol=1e-9, atol=1e-18):
+                        modes[(stp, "other step sequence")] = modes.get((stp, "other step sequence"), 0) + 1
+                        continue   # the step sequences differ (rounding in the error test): the grid run above compared the waveforms
+                    # same steps: row by row — from row 1: the SIN sources here have dc = 0 and a waveform that starts elsewhere, and row 0
+                    # of a source-held node is the :dcop value in the oracle, the waveform at t = 0 (what the re-initialisation in
+                    # transient mode, src/dcop.jl step 3, leaves) in the engine
+                    err = float(np.abs(ve[:, 1:, 0] - vo[:, 1:]).max())
+                    tol = 2e-4
                 if not err < tol * max(1.0, float(np.abs(vo).max())):
                     fails.append((seed, "tran v", stp, key, err, float(np.abs(vo).max()), ste["naccept"], sto["naccept"]))
         done += 1
