@@ -25,7 +25,7 @@ for seed in range(first, first + n_seeds):
     if (seed - first) % 250 == 0:
         print("progress: seed %d, %d compared, %d failures, %.0f s" % (seed, done, len(fails), time.time() - t_start), flush=True)
     rng = np.random.default_rng(seed)
-    c = _random_circuit(rng, int(rng.integers(3, int(os.environ.get("FUZZ_MAX_NODES", "16")))), with_mos=seed % 2 == 0)
+    c = _random_circuit(rng, int(rng.integers(3, int(os.environ.get("FUZZ_MAX_NODES", "16")))), with_mos=(seed % 2 == 0 or os.environ.get("FUZZ_ALWAYS_MOS") is not None))
     c.observe_all_nodes()
     try:
         o = Oracle(c)
