@@ -12,7 +12,7 @@ from oracle_binding import Oracle  # noqa: E402
 from test_gpu_parity import _random_circuit, canon, reduce_rows  # noqa: E402
 seed = int(sys.argv[1])
 rng = np.random.default_rng(seed)
-c = _random_circuit(rng, int(rng.integers(3, int(os.environ.get("FUZZ_MAX_NODES", "16")))), with_mos=seed % 2 == 0)
+c = _random_circuit(rng, int(rng.integers(3, int(os.environ.get("FUZZ_MAX_NODES", "16")))), with_mos=(seed % 2 == 0 or os.environ.get("FUZZ_ALWAYS_MOS") is not None))
 c.observe_all_nodes()
 e, o = EngineCircuit(c), Oracle(c)
 nu, nk, bu = e.maps()

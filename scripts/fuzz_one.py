@@ -13,7 +13,7 @@ from test_gpu_parity import _random_circuit  # noqa: E402
 seed, stp = int(sys.argv[1]), sys.argv[2]
 max_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rng = np.random.default_rng(seed)
-c = _random_circuit(rng, int(rng.integers(3, int(os.environ.get("FUZZ_MAX_NODES", "16")))), with_mos=seed % 2 == 0)
+c = _random_circuit(rng, int(rng.integers(3, int(os.environ.get("FUZZ_MAX_NODES", "16")))), with_mos=(seed % 2 == 0 or os.environ.get("FUZZ_ALWAYS_MOS") is not None))
 c.observe_all_nodes()
 sv = np.array([1e-7, 2e-7, 3.5e-7, 5.5e-7, 6e-7, 1e-6])
 o = Oracle(c)
